@@ -1,0 +1,197 @@
+/*
+ * sagnn.h — C ABI of libsagnn.so: SelfGNN's per-time-interval graph propagation and
+ * interval fusion as hand-written HIP kernels for MI355X (gfx950).
+ *
+ * The reference (LIU-YUXI/SA-GNN, TF1 graph mode) has no FFI: its seam is the Python
+ * method Recommender.messagePropagate (model.py:80-92) and the loop around it in
+ * Recommender.ours (model.py:118-155). Each entry point below names the reference
+ * lines it replaces. The Python host in sa-gnn_amd/ binds these with ctypes
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - Plain C: pointers, sizes, strides in ELEMENTS. No torch / HIP types.
+ *     `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - Every `d_*` / unprefixed tensor pointer is DEVICE memory owned by the caller.
+ *     `h_*` pointers are HOST memory. The library never frees or retains caller memory
+ *     except the two CSR device pointers kept inside a plan object.
+ *   - All floating point is fp32, all indices int32 (reference: fp32 / int32 throughout).
+ *   - Calls are asynchronous on `stream`; the library never synchronises except in
+ *     sagnn_spmm_plan_create (one-off upload of plan metadata).
+ *   - Return value: 0 = OK; negative = argument error (SAGNN_ERR_*); positive = hipError_t.
+ *     No C++ exception crosses the ABI. sagnn_last_error() gives a thread-local message.
+ *   - Feature rows must be 16-byte aligned: base pointers 16-B aligned, every ld a
+ *     multiple of 4, d a multiple of 4 with 4 <= d <= 256.
+ */
+#ifndef SAGNN_H
+#define SAGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAGNN_VERSION 10100 /* 1.1.0 */
+
+enum {
+  SAGNN_OK = 0,
+  SAGNN_ERR_NULL = -1,      /* a required pointer is NULL */
+  SAGNN_ERR_DIM = -2,       /* d / t / heads unsupported */
+  SAGNN_ERR_ALIGN = -3,     /* pointer or leading dimension not 16-byte aligned */
+  SAGNN_ERR_CSR = -4,       /* rowptr not monotone, rowptr[n]!=nnz, colidx out of range */
+  SAGNN_ERR_ARG = -5,       /* any other inconsistent argument */
+  SAGNN_ERR_WORKSPACE = -6, /* workspace missing or too small */
+  SAGNN_ERR_NOMEM = -7      /* host allocation failed */
+};
+
+int sagnn_version(void);
+
+/* Copies the calling thread's last error text (NUL-terminated, truncated to cap) and
+ * returns its full length. */
+size_t sagnn_last_error(char* buf, size_t cap);
+
+/* ------------------------------------------------------------------------------------
+ * CSR validation (host). Replaces nothing in the reference: TF-CPU raised
+ * InvalidArgument from GatherV2 on an out-of-range index (model.py:86); the kernels do
+ * not bounds-check, so the host wrapper calls this once per adjacency at load time.
+ * -------------------------------------------------------------------------------- */
+int sagnn_csr_check_host(const int32_t* h_rowptr, const int32_t* h_colidx,
+                         int64_t n_rows, int64_t n_src, int64_t nnz);
+
+/* ------------------------------------------------------------------------------------
+ * SpMM plan: per-adjacency metadata, built once (the reference bakes each adjacency into
+ * the TF graph as a constant SparseTensor once, model.py:227-237).
+ *
+ * Rows are handled by degree class:
+ *   deg <= short_thresh            one lane-group (d/4 lanes) per row, several rows per wave
+ *   short < deg <= long_thresh     one whole wavefront per row
+ *   deg > long_thresh              split into chunks of <= chunk_edges edges, one wavefront
+ *                                  per chunk into a partial-sum workspace, then a fix-up
+ *                                  pass adds the partials in chunk order (deterministic,
+ *                                  no atomics)
+ * Only the third class needs stored metadata (the chunk list).
+ * -------------------------------------------------------------------------------- */
+typedef struct sagnn_spmm_plan sagnn_spmm_plan;
+
+typedef struct sagnn_spmm_tuning {
+  int32_t short_thresh;  /* 0 = default */
+  int32_t long_thresh;   /* 0 = default */
+  int32_t chunk_edges;   /* 0 = default; rounded up to a multiple of 64 */
+  int32_t reserved;
+} sagnn_spmm_tuning;
+
+typedef struct sagnn_spmm_plan_info {
+  int64_t n_rows, n_src, nnz;
+  int64_t n_long_rows;   /* rows with deg > long_thresh */
+  int64_t n_chunks;      /* total chunks over all long rows */
+  int32_t short_thresh, long_thresh, chunk_edges;
+  int32_t max_degree;
+  int32_t on_device;     /* 1 if chunk metadata was uploaded (d_rowptr given) */
+  int32_t reserved;
+} sagnn_spmm_plan_info;
+
+/* h_rowptr: host copy of rowptr [n_rows+1] (read during the call only).
+ * d_rowptr/d_colidx: device CSR, must outlive the plan. Pass both NULL to build a
+ * host-only plan (no GPU touched) — used by the CPU test-suite to check the chunking. */
+int sagnn_spmm_plan_create(const int32_t* h_rowptr, const int32_t* d_rowptr,
+                           const int32_t* d_colidx, int64_t n_rows, int64_t n_src,
+                           int64_t nnz, const sagnn_spmm_tuning* tuning /* nullable */,
+                           sagnn_spmm_plan** plan_out);
+int sagnn_spmm_plan_destroy(sagnn_spmm_plan* plan);
+int sagnn_spmm_plan_get_info(const sagnn_spmm_plan* plan, sagnn_spmm_plan_info* info);
+/* Copies the chunk list to host arrays of capacity `cap` entries each (cap >= n_chunks).
+ * chunk i covers edges [e_begin[i], e_end[i]) of row rows[i]; chunks of one row are
+ * consecutive and in edge order. */
+int sagnn_spmm_plan_copy_chunks(const sagnn_spmm_plan* plan, int32_t* rows, int32_t* e_begin,
+                                int32_t* e_end, int64_t cap);
+/* Bytes of device workspace sagnn_spmm_f32 needs for feature width d (0 if no long rows). */
+size_t sagnn_spmm_workspace_bytes(const sagnn_spmm_plan* plan, int d);
+
+/* ------------------------------------------------------------------------------------
+ * sagnn_spmm_f32 — replaces Recommender.messagePropagate (model.py:80-92) together with
+ * the residual add (model.py:124-125) and the running tf.add_n (model.py:126-127):
+ *
+ *     s[r,:]   = sum over edges (r,c) of X[c,:]          GatherV2 + SegmentSum (:86-87);
+ *                                                        rows without edges give 0 (:87-91)
+ *     y[r,:]   = max(leaky*s, s) + residual[r,:]         Activate 'leakyRelu' (NNLayers.py:136)
+ *                                                        + embs[-1]          (model.py:124)
+ *     out[r,:]     = y            (if out     != NULL)
+ *     acc_out[r,:] = acc_in + y   (if acc_out != NULL; acc_in NULL means 0)
+ *
+ * Edge values are ignored, as in the reference (model.py:84, :86). residual may be NULL.
+ * acc_in may alias residual and may alias acc_out (in-place running sum). out/acc_out
+ * must not alias X. At least one of out/acc_out is required.
+ * -------------------------------------------------------------------------------- */
+int sagnn_spmm_f32(const sagnn_spmm_plan* plan, const float* X, int64_t ldx, int d,
+                   const float* residual, int64_t ldr, float leaky, float* out, int64_t ldo,
+                   const float* acc_in, int64_t ld_acc_in, float* acc_out, int64_t ld_acc_out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * sagnn_gnn_interval_f32 — one iteration k of the loop model.py:118-129 (L layers, both
+ * directions, simultaneous update, residuals, add_n), 2*L SpMM launches issued from C.
+ *
+ *   e_u^0 = u0, e_i^0 = i0
+ *   e_u^{l+1} = leaky(A   e_i^l) + e_u^l        plan_user: rows = users, cols = items
+ *   e_i^{l+1} = leaky(A^T e_u^l) + e_i^l        plan_item: rows = items, cols = users
+ *   user_out = sum_{l=0..L} e_u^l ;  item_out = sum_{l=0..L} e_i^l
+ *
+ * scratch_u: [2, U, d] floats, scratch_i: [2, I, d] floats (ping-pong layer outputs; may be
+ * NULL when n_layers <= 1). user_out/item_out are written with row strides ld_uo/ld_io so
+ * the caller can target row k of an [N, T, d] slab directly (replaces tf.stack +
+ * tf.transpose, model.py:131-134).
+ * -------------------------------------------------------------------------------- */
+int sagnn_gnn_interval_f32(const sagnn_spmm_plan* plan_user, const sagnn_spmm_plan* plan_item,
+                           const float* u0, int64_t ld_u0, const float* i0, int64_t ld_i0,
+                           int d, int n_layers, float leaky, float* scratch_u, float* scratch_i,
+                           float* user_out, int64_t ld_uo, float* item_out, int64_t ld_io,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Interval fusion (model.py:135-155). x is [n, t, d] with row stride ld_n (elements)
+ * between nodes and d between intervals.
+ *
+ * sagnn_lstm_fwd_f32 — dynamic_rnn(MultiRNNCell([DropoutWrapper(BasicLSTMCell(d))]))
+ *   (model.py:135-146) at keep probability 1: TF 1.14 BasicLSTMCell, kernel W [2d, 4d]
+ *   row-major (rows 0..d-1 multiply x_t, rows d..2d-1 multiply h), bias b [4d], gate
+ *   order i, j, f, o;  c' = c*sigmoid(f + forget_bias) + sigmoid(i)*tanh(j);
+ *   h' = tanh(c')*sigmoid(o); zero initial state. Writes h for every step: [n, t, d].
+ *   drop_scale (nullable) [n, t, d] multiplies the EMITTED h only (DropoutWrapper's
+ *   output_keep_prob; the recurrent state is not dropped).
+ *
+ * sagnn_layernorm_td_f32 — tf.contrib.layers.layer_norm defaults (model.py:152-153):
+ *   mean/variance over (t, d) jointly per node, gamma/beta [d], eps = 1e-12 inside rsqrt.
+ *
+ * sagnn_mhsa_mean_f32 — MultiHeadSelfAttention.attention (Utils/attention.py:55-78) with
+ *   ScaledDotProductAttention (:35-45), then tf.reduce_mean(axis=1) (model.py:154-155):
+ *   Q/K/V = x@W+b (W [d, d] row-major, in x out), heads of d_k = d/heads,
+ *   scores = exp(Q K^T / sqrt(d_k)) (no max subtraction), attn = scores/(rowsum + 1e-8),
+ *   context = attn V, mean over the t query positions -> out [n, d].
+ *
+ * sagnn_interval_fusion_f32 — the three stages back to back on `stream` with the LSTM
+ *   output kept in a caller-provided workspace (sagnn_interval_fusion_workspace_bytes) and
+ *   normalised in place; only out [n, d] is a result.
+ * -------------------------------------------------------------------------------- */
+int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t n, int t, int d, const float* W,
+                       const float* b, float forget_bias, const float* drop_scale, float* h,
+                       int64_t ld_h, void* stream);
+int sagnn_layernorm_td_f32(const float* x, int64_t ld_n, int64_t n, int t, int d,
+                           const float* gamma, const float* beta, float eps, float* y,
+                           int64_t ld_y, void* stream);
+int sagnn_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t n, int t, int d, int heads,
+                        const float* Wq, const float* bq, const float* Wk, const float* bk,
+                        const float* Wv, const float* bv, float* out, int64_t ld_out,
+                        void* stream);
+int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t n, int t, int d, int heads,
+                              const float* lstm_W, const float* lstm_b, float forget_bias,
+                              const float* ln_gamma, const float* ln_beta, float ln_eps,
+                              const float* Wq, const float* bq, const float* Wk, const float* bk,
+                              const float* Wv, const float* bv, float* out, int64_t ld_out,
+                              void* workspace, size_t workspace_bytes, void* stream);
+size_t sagnn_interval_fusion_workspace_bytes(int64_t n, int t, int d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAGNN_H */

@@ -1,0 +1,253 @@
+"""CPU restatement of SelfGNN's interval-propagation hot path — TEST INFRASTRUCTURE ONLY.
+
+This module is the checker for the HIP kernels in sa-gnn_amd/csrc. Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may import it; the product path never
+does (sa-gnn_amd/ raises if libsagnn.so is missing instead of falling back here).
+
+Every function restates one piece of the reference (LIU-YUXI/SA-GNN, TF1) op for op in numpy,
+fp32 unless `dtype` says otherwise, and cites the file:line it follows. The arithmetic of the
+reference lives in TensorFlow 1.14.0 (requirements.txt:4), which is not installable here
+(Python 3.10, no network), so TF-op semantics are restated from their documented behaviour:
+GatherV2, SegmentSum (output rows = max(id)+1, sequential sum per segment), Pad, Maximum, AddN,
+BasicLSTMCell (gate order i, j, f, o; forget_bias 1.0), contrib.layers.layer_norm
+(begin_norm_axis=1, begin_params_axis=-1, eps 1e-12), layers.dense.
+
+PARITY PINNING: the reference ships no tests, golden vectors or expected outputs (SURVEY.md §4,
+§8c). What IS pinned against the running reference: transToLsts / transpose (DataHandler.py
+imports here; tests/golden/make_golden.py records their outputs). The TF-side arithmetic is
+"parity unpinned": it is cross-checked against an independent formulation (scipy pattern-CSR @
+dense, torch.nn.LSTMCell-free hand-rolled recurrences) in tests/test_oracle.py, not against TF.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+
+# ----------------------------------------------------------------------------------------------
+# Data side: DataHandler.py:9-11, 47-69
+# ----------------------------------------------------------------------------------------------
+
+
+def transpose(mat):
+    """DataHandler.transpose (DataHandler.py:9-11): CSR -> COO -> transpose -> CSR.
+
+    scipy's COO->CSR conversion sums duplicate (row, col) entries and sorts each row, so a
+    duplicated edge counts once in the transposed adjacency but twice in the forward one."""
+    return sp.csr_matrix(sp.coo_matrix(mat).transpose())
+
+
+def trans_to_lsts(mat, norm: bool = False):
+    """DataHandler.transToLsts (DataHandler.py:47-69), mask=False.
+
+    Returns (indices int32 [nnz, 2] as (row, col) in stored CSR order, data int32 [nnz], shape).
+    With norm=True the reference multiplies the degree normalisers into an int32 array
+    (DataHandler.py:51, 56-59), so every value truncates toward zero; the values are dead
+    anyway (model.py:84). An empty matrix yields one phantom edge (0, 0) (DataHandler.py:66-68)."""
+    shape = [mat.shape[0], mat.shape[1]]
+    coo = sp.coo_matrix(mat)
+    indices = np.stack([coo.row, coo.col], axis=1).astype(np.int32).reshape(-1, 2)
+    data = coo.data.astype(np.int32)
+    if norm and len(data):
+        row_d = np.squeeze(np.array(1 / (np.sqrt(np.sum(mat, axis=1) + 1e-8) + 1e-8)), axis=1)
+        col_d = np.squeeze(np.array(1 / (np.sqrt(np.sum(mat, axis=0) + 1e-8) + 1e-8)), axis=0)
+        # element-wise, in the reference's order: int32 <- int32 * float64 * float64 (truncates)
+        scaled = data.astype(np.float64) * row_d[indices[:, 0]] * col_d[indices[:, 1]]
+        data = np.trunc(scaled).astype(np.int32)
+    if indices.shape[0] == 0:
+        indices = np.array([[0, 0]], dtype=np.int32)
+        data = np.array([0], dtype=np.int32)
+    return indices, data, shape
+
+
+# ----------------------------------------------------------------------------------------------
+# Propagation: model.py:80-92, 118-134
+# ----------------------------------------------------------------------------------------------
+
+
+def segment_sum(data: np.ndarray, segment_ids: np.ndarray) -> np.ndarray:
+    """tf.math.segment_sum: sorted ids, output has max(id)+1 rows, missing ids give zero rows.
+    Each segment is accumulated sequentially in input order (the TF CPU kernel's order)."""
+    if len(segment_ids) == 0:
+        return np.zeros((0, data.shape[1]), dtype=data.dtype)
+    if np.any(np.diff(segment_ids) < 0):
+        raise ValueError("segment ids are not sorted")  # TF raises InvalidArgument
+    n_out = int(segment_ids[-1]) + 1
+    out = np.zeros((n_out, data.shape[1]), dtype=data.dtype)
+    for e in range(len(segment_ids)):  # pure-Python loop: small cases only
+        out[segment_ids[e]] += data[e]
+    return out
+
+
+def segment_sum_fast(data: np.ndarray, segment_ids: np.ndarray) -> np.ndarray:
+    """Same result up to fp32 summation order (np.add.reduceat); for the larger test cases."""
+    if len(segment_ids) == 0:
+        return np.zeros((0, data.shape[1]), dtype=data.dtype)
+    n_out = int(segment_ids[-1]) + 1
+    out = np.zeros((n_out, data.shape[1]), dtype=data.dtype)
+    starts = np.flatnonzero(np.r_[True, np.diff(segment_ids) != 0])
+    out[segment_ids[starts]] = np.add.reduceat(data, starts, axis=0)
+    return out
+
+
+def leaky_relu(x: np.ndarray, leaky: float) -> np.ndarray:
+    """ActivateHelp('leakyRelu') = tf.maximum(leaky*data, data) (Utils/NNLayers.py:135-136)."""
+    return np.maximum(np.asarray(leaky, dtype=x.dtype) * x, x)
+
+
+def message_propagate(srclats: np.ndarray, indices: np.ndarray, n_out: int, leaky: float,
+                      exact_order: bool = False) -> np.ndarray:
+    """Recommender.messagePropagate (model.py:80-92).
+
+    src = indices[:, 1], tgt = indices[:, 0] (:82-83); gather (:86); segment_sum + 100 rows of
+    zero padding (:87); rows 0..n_out-1 (:88-91); leaky-ReLU (:92). TF-CPU raises when n_out
+    exceeds max(tgt)+1+100 (GatherV2 out of range); so does this."""
+    src = indices[:, 1]
+    tgt = indices[:, 0]
+    gathered = srclats[src]                                            # GatherV2 [nnz, d]
+    seg = (segment_sum if exact_order else segment_sum_fast)(gathered, tgt)
+    lat = np.concatenate([seg, np.zeros((100, srclats.shape[1]), dtype=srclats.dtype)], axis=0)
+    if n_out > lat.shape[0]:
+        raise IndexError(
+            f"gather of rows 0..{n_out - 1} from {lat.shape[0]} rows: the last connected row is "
+            "more than 100 below N (TF-CPU InvalidArgument; TF-GPU returns zeros)")
+    return leaky_relu(lat[:n_out], leaky)
+
+
+def message_propagate_zero_fill(srclats, indices, n_out, leaky):
+    """The build's contract for the >100-trailing-empty-rows case: exactly
+    [n_out, d], isolated rows are leaky(0) = 0 (what TF-GPU returns)."""
+    src = indices[:, 1]
+    tgt = indices[:, 0]
+    seg = segment_sum_fast(srclats[src], tgt)
+    lat = np.zeros((n_out, srclats.shape[1]), dtype=srclats.dtype)
+    m = min(n_out, seg.shape[0])
+    lat[:m] = seg[:m]
+    return leaky_relu(lat, leaky)
+
+
+def gnn_interval(u0, i0, adj_idx, tp_idx, n_layers: int, leaky: float, zero_fill: bool = True):
+    """One k of the loop model.py:118-129: both directions read layer l (simultaneous update,
+    a_emb1 is built from embs0[-1] before :124 appends), residual adds (:124-125), add_n (:126-127)."""
+    mp = message_propagate_zero_fill if zero_fill else message_propagate
+    embs0, embs1 = [u0], [i0]
+    for _ in range(n_layers):
+        a0 = mp(embs1[-1], adj_idx, u0.shape[0], leaky)
+        a1 = mp(embs0[-1], tp_idx, i0.shape[0], leaky)
+        embs0.append(a0 + embs0[-1])
+        embs1.append(a1 + embs1[-1])
+    user = embs0[0]
+    for e in embs0[1:]:
+        user = user + e                                                # AddN, left to right
+    item = embs1[0]
+    for e in embs1[1:]:
+        item = item + e
+    return user, item
+
+
+def gnn_stack(u_embed, i_embed, adj_list, tp_list, n_layers: int, leaky: float):
+    """model.py:118-134: all T intervals, tf.stack + tf.transpose -> [N, T, d]."""
+    users, items = [], []
+    for k in range(len(adj_list)):
+        u, i = gnn_interval(u_embed[k], i_embed[k], adj_list[k], tp_list[k], n_layers, leaky)
+        users.append(u)
+        items.append(i)
+    return np.stack(users, 0).transpose(1, 0, 2), np.stack(items, 0).transpose(1, 0, 2)
+
+
+# ----------------------------------------------------------------------------------------------
+# Interval fusion: model.py:135-155, Utils/attention.py:31-78
+# ----------------------------------------------------------------------------------------------
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def basic_lstm(x: np.ndarray, kernel: np.ndarray, bias: np.ndarray, forget_bias: float = 1.0,
+               drop_scale: np.ndarray | None = None) -> np.ndarray:
+    """dynamic_rnn over MultiRNNCell([DropoutWrapper(BasicLSTMCell(d))]) (model.py:135-146).
+
+    TF 1.14 BasicLSTMCell.call: gate_inputs = concat([x_t, h], 1) @ kernel + bias;
+    i, j, f, o = split(gate_inputs, 4, axis=1);
+    new_c = c*sigmoid(f + forget_bias) + sigmoid(i)*tanh(j); new_h = tanh(new_c)*sigmoid(o).
+    Zero initial state. DropoutWrapper(output_keep_prob) scales only the emitted h."""
+    n, t, d = x.shape
+    h = np.zeros((n, d), dtype=x.dtype)
+    c = np.zeros((n, d), dtype=x.dtype)
+    fb = np.asarray(forget_bias, dtype=x.dtype)
+    outs = []
+    for ts in range(t):
+        g = np.concatenate([x[:, ts, :], h], axis=1) @ kernel + bias
+        gi, gj, gf, go = np.split(g, 4, axis=1)
+        c = c * _sigmoid(gf + fb) + _sigmoid(gi) * np.tanh(gj)
+        h = np.tanh(c) * _sigmoid(go)
+        outs.append(h if drop_scale is None else h * drop_scale[:, ts, :])
+    return np.stack(outs, axis=1)
+
+
+def layer_norm_td(x: np.ndarray, gamma: np.ndarray, beta: np.ndarray, eps: float = 1e-12):
+    """tf.contrib.layers.layer_norm defaults (model.py:152-153): moments over axes (1, 2) per
+    node (tf.nn.moments: population variance around the mean), then tf.nn.batch_normalization:
+    inv = rsqrt(var + eps) * gamma;  y = x*inv + (beta - mean*inv)."""
+    mean = x.mean(axis=(1, 2), keepdims=True, dtype=x.dtype)
+    var = np.square(x - mean).mean(axis=(1, 2), keepdims=True, dtype=x.dtype)
+    inv = (1.0 / np.sqrt(var + np.asarray(eps, dtype=x.dtype))).astype(x.dtype) * gamma
+    return x * inv + (beta - mean * inv)
+
+
+def mhsa(x, wq, bq, wk, bk, wv, bv, heads: int):
+    """MultiHeadSelfAttention.attention (Utils/attention.py:55-78) with
+    ScaledDotProductAttention.attention (:35-45): three tf.layers.dense with bias, reshape to
+    [N, heads, T, d_k], scores = exp(QK^T/sqrt(d_k)) with no max subtraction (:38-39),
+    attn = scores/(sum + 1e-8) (:43), context = attn @ V (:44), heads merged (:77)."""
+    n, t, d = x.shape
+    dk = d // heads
+    q = (x @ wq + bq).reshape(n, t, heads, dk).transpose(0, 2, 1, 3)
+    k = (x @ wk + bk).reshape(n, t, heads, dk).transpose(0, 2, 1, 3)
+    v = (x @ wv + bv).reshape(n, t, heads, dk).transpose(0, 2, 1, 3)
+    scores = np.exp((q @ k.transpose(0, 1, 3, 2)) / np.asarray(np.sqrt(dk), dtype=x.dtype))
+    attn = scores / (scores.sum(axis=-1, keepdims=True) + np.asarray(1e-8, dtype=x.dtype))
+    ctx = attn @ v
+    return ctx.transpose(0, 2, 1, 3).reshape(n, t, heads * dk)
+
+
+def interval_fusion(x, p: dict, heads: int):
+    """model.py:135-155 for one node type: LSTM -> layer_norm -> MHSA -> reduce_mean(axis=1).
+    p holds lstm_W [2d,4d], lstm_b [4d], ln_gamma [d], ln_beta [d], Wq/bq/Wk/bk/Wv/bv."""
+    h = basic_lstm(x, p["lstm_W"], p["lstm_b"], 1.0)
+    y = layer_norm_td(h, p["ln_gamma"], p["ln_beta"], 1e-12)
+    a = mhsa(y, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], heads)
+    return a.mean(axis=1, dtype=x.dtype)
+
+
+# ----------------------------------------------------------------------------------------------
+# Parameter initialisers: Utils/NNLayers.py:43-68 (xavier), TF defaults for LSTM / dense / LN
+# ----------------------------------------------------------------------------------------------
+
+
+def xavier_uniform(shape, rng: np.random.Generator, dtype=np.float32):
+    """tf.contrib.layers.xavier_initializer(uniform=True): limit = sqrt(6/(fan_in+fan_out));
+    for rank > 2 both fans are multiplied by prod(shape[:-2]) (so [T, N, d] has fan_in = T*N)."""
+    shape = tuple(int(s) for s in shape)
+    if len(shape) == 1:
+        fan_in = fan_out = shape[0]
+    else:
+        rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+        fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(dtype)
+
+
+def init_fusion_params(d: int, rng: np.random.Generator, dtype=np.float32) -> dict:
+    """Shapes and initial values as TF creates them: BasicLSTMCell kernel [2d, 4d] glorot
+    uniform, bias zeros; layer_norm gamma ones / beta zeros; dense kernels xavier, biases zeros.
+    Biases and beta get small random values instead of zeros so tests exercise them."""
+    return {
+        "lstm_W": xavier_uniform((2 * d, 4 * d), rng, dtype),
+        "lstm_b": (0.1 * rng.standard_normal(4 * d)).astype(dtype),
+        "ln_gamma": (1.0 + 0.1 * rng.standard_normal(d)).astype(dtype),
+        "ln_beta": (0.1 * rng.standard_normal(d)).astype(dtype),
+        "Wq": xavier_uniform((d, d), rng, dtype), "bq": (0.1 * rng.standard_normal(d)).astype(dtype),
+        "Wk": xavier_uniform((d, d), rng, dtype), "bk": (0.1 * rng.standard_normal(d)).astype(dtype),
+        "Wv": xavier_uniform((d, d), rng, dtype), "bv": (0.1 * rng.standard_normal(d)).astype(dtype),
+    }

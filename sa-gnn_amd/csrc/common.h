@@ -1,0 +1,33 @@
+// Shared host-side helpers for libsagnn.so (error reporting, argument checks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "sagnn.h"
+
+namespace sagnn {
+
+std::string& last_error_slot();
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int hip_fail(hipError_t e, const char* what);
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define SAGNN_HIP_TRY(expr)                                   \
+  do {                                                        \
+    hipError_t _e = (expr);                                   \
+    if (_e != hipSuccess) return ::sagnn::hip_fail(_e, #expr); \
+  } while (0)
+
+// Lanes per feature row: each lane owns one float4, so a row of d floats needs d/4 lanes,
+// rounded up to a power of two that divides the 64-lane wavefront.
+inline int lanes_per_row(int d) {
+  int need = (d + 3) / 4;
+  int lpr = 8;
+  while (lpr < need) lpr <<= 1;
+  return lpr;  // 8, 16, 32 or 64 for d <= 256
+}
+
+}  // namespace sagnn

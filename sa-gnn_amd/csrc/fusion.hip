@@ -1,0 +1,280 @@
+// Interval fusion for gfx950 (reference model.py:135-155): BasicLSTMCell over the T interval
+// embeddings of every node, layer-norm over (T, d), multi-head self-attention over T with the
+// reference's exp/(sum + 1e-8) normalisation, mean over T.
+//
+// This file holds the VALU (fp32 FMA) formulation: one thread per (node, hidden unit), weights
+// streamed through L2, activations staged in LDS. fusion_mfma.hip holds the MFMA formulation
+// of the two GEMM-shaped stages; both are checked against the same oracle.
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kLstmRowsPerThread = 4;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// TF 1.14 BasicLSTMCell.call (rnn_cell_impl.py): gate_inputs = [x, h] @ W + b;
+// i, j, f, o = split(gate_inputs, 4); c' = c*sigmoid(f + forget_bias) + sigmoid(i)*tanh(j);
+// h' = tanh(c')*sigmoid(o).
+__global__ void lstm_fwd_valu_kernel(const float* __restrict__ x, int64_t ld_n, int64_t n, int t,
+                                     int d, const float* __restrict__ W,
+                                     const float* __restrict__ b, float forget_bias,
+                                     const float* __restrict__ drop, float* __restrict__ h_out,
+                                     int64_t ld_h) {
+  extern __shared__ float sm[];  // [rows_per_block][2d]: x_t | h
+  constexpr int RPT = kLstmRowsPerThread;
+  const int j = threadIdx.x % d;
+  const int rs = threadIdx.x / d;
+  const int slots = blockDim.x / d;
+  const int rows_pb = slots * RPT;
+  const int64_t row_base = (int64_t)blockIdx.x * rows_pb;
+  const int d2 = 2 * d, d4 = 4 * d;
+
+  float c[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) c[r] = 0.f;
+  for (int i = threadIdx.x; i < rows_pb * d; i += blockDim.x) sm[(i / d) * d2 + d + (i % d)] = 0.f;
+
+  const float b_i = b[j], b_j = b[d + j], b_f = b[2 * d + j], b_o = b[3 * d + j];
+  for (int ts = 0; ts < t; ++ts) {
+    for (int i = threadIdx.x; i < rows_pb * d; i += blockDim.x) {
+      const int r = i / d, k = i % d;
+      const int64_t row = row_base + r;
+      sm[r * d2 + k] = row < n ? x[row * ld_n + (int64_t)ts * d + k] : 0.f;
+    }
+    __syncthreads();
+    float gi[RPT], gj[RPT], gf[RPT], go[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      gi[r] = 0.f;
+      gj[r] = 0.f;
+      gf[r] = 0.f;
+      go[r] = 0.f;
+    }
+    for (int k = 0; k < d2; ++k) {
+      const float* wr = W + (int64_t)k * d4 + j;
+      const float wi = wr[0], wj = wr[d], wf = wr[2 * d], wo = wr[3 * d];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const float a = sm[(rs * RPT + r) * d2 + k];
+        gi[r] = fmaf(a, wi, gi[r]);
+        gj[r] = fmaf(a, wj, gj[r]);
+        gf[r] = fmaf(a, wf, gf[r]);
+        go[r] = fmaf(a, wo, go[r]);
+      }
+    }
+    __syncthreads();  // every thread has finished reading x_t | h
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int lr = rs * RPT + r;
+      const int64_t row = row_base + lr;
+      const float cn = c[r] * sigmoidf_(gf[r] + b_f + forget_bias) + sigmoidf_(gi[r] + b_i) * tanhf(gj[r] + b_j);
+      const float hn = tanhf(cn) * sigmoidf_(go[r] + b_o);
+      c[r] = cn;
+      sm[lr * d2 + d + j] = hn;
+      if (row < n) {
+        const int64_t o = row * ld_h + (int64_t)ts * d + j;
+        h_out[o] = drop ? hn * drop[row * (int64_t)t * d + (int64_t)ts * d + j] : hn;
+      }
+    }
+  }
+}
+
+// tf.contrib.layers.layer_norm(begin_norm_axis=1, begin_params_axis=-1): moments over (t, d),
+// then tf.nn.batch_normalization: inv = rsqrt(var + eps) * gamma; y = x*inv + (beta - mean*inv).
+// One wavefront per node.
+// x and y may alias (in-place): each element is read and written by the same lane.
+__global__ void layernorm_td_kernel(const float* x, int64_t ld_n, int64_t n, int t, int d,
+                                    const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, float eps, float* y,
+                                    int64_t ld_y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t node = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (node >= n) return;
+  const int td = t * d;
+  const float* xr = x + node * ld_n;
+  float s = 0.f;
+  for (int i = lane; i < td; i += 64) s += xr[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  const float mean = s / (float)td;
+  float v = 0.f;
+  for (int i = lane; i < td; i += 64) {
+    const float dlt = xr[i] - mean;
+    v = fmaf(dlt, dlt, v);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  const float rstd = rsqrtf(v / (float)td + eps);
+  float* yr = y + node * ld_y;
+  for (int i = lane; i < td; i += 64) {
+    const int k = i % d;
+    const float inv = rstd * gamma[k];
+    yr[i] = xr[i] * inv + (beta[k] - mean * inv);
+  }
+}
+
+// MultiHeadSelfAttention.attention + reduce_mean over the query axis. d threads per node.
+__global__ void mhsa_mean_valu_kernel(const float* __restrict__ x, int64_t ld_n, int64_t n, int t,
+                                      int d, int heads, const float* __restrict__ Wq,
+                                      const float* __restrict__ bq, const float* __restrict__ Wk,
+                                      const float* __restrict__ bk, const float* __restrict__ Wv,
+                                      const float* __restrict__ bv, float* __restrict__ out,
+                                      int64_t ld_out) {
+  extern __shared__ float sm[];  // per slot: y | q | k | v, each [t][d]
+  const int j = threadIdx.x % d;
+  const int slot = threadIdx.x / d;
+  const int slots = blockDim.x / d;
+  const int td = t * d;
+  float* ys = sm + (size_t)slot * 4 * td;
+  float* qs = ys + td;
+  float* ks = qs + td;
+  float* vs = ks + td;
+  const int dk = d / heads;
+  const int hoff = (j / dk) * dk;
+  const float scale = 1.f / sqrtf((float)dk);
+
+  for (int64_t node0 = (int64_t)blockIdx.x * slots; node0 < n; node0 += (int64_t)gridDim.x * slots) {
+    const int64_t node = node0 + slot;
+    const bool valid = node < n;
+    for (int ts = 0; ts < t; ++ts) ys[ts * d + j] = valid ? x[node * ld_n + (int64_t)ts * d + j] : 0.f;
+    __syncthreads();
+    for (int ts = 0; ts < t; ++ts) {
+      float q = 0.f, k = 0.f, v = 0.f;
+      for (int kk = 0; kk < d; ++kk) {
+        const float a = ys[ts * d + kk];
+        q = fmaf(a, Wq[kk * d + j], q);
+        k = fmaf(a, Wk[kk * d + j], k);
+        v = fmaf(a, Wv[kk * d + j], v);
+      }
+      qs[ts * d + j] = q + bq[j];
+      ks[ts * d + j] = k + bk[j];
+      vs[ts * d + j] = v + bv[j];
+    }
+    __syncthreads();
+    float o = 0.f;
+    for (int tq = 0; tq < t; ++tq) {
+      float rowsum = 0.f, ctx = 0.f;
+      for (int s = 0; s < t; ++s) {
+        float dot = 0.f;
+        for (int c = 0; c < dk; ++c) dot = fmaf(qs[tq * d + hoff + c], ks[s * d + hoff + c], dot);
+        const float e = expf(dot * scale);
+        rowsum += e;
+        ctx = fmaf(e, vs[s * d + j], ctx);
+      }
+      o += ctx / (rowsum + 1e-8f);
+    }
+    if (valid) out[node * ld_out + j] = o / (float)t;
+    __syncthreads();
+  }
+}
+
+int check_dims(int64_t n, int t, int d) {
+  if (n < 0) return sagnn::fail(SAGNN_ERR_ARG, "n = %lld < 0", (long long)n);
+  if (t < 1 || t > 64) return sagnn::fail(SAGNN_ERR_DIM, "t = %d: need 1..64", t);
+  if (d < 4 || d > 256 || (d & 3)) return sagnn::fail(SAGNN_ERR_DIM, "d = %d: need a multiple of 4 in [4, 256]", d);
+  return SAGNN_OK;
+}
+
+}  // namespace
+
+namespace sagnn {
+
+int lstm_fwd_valu(const float* x, int64_t ld_n, int64_t n, int t, int d, const float* W,
+                  const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
+                  hipStream_t s) {
+  const int slots = kBlock / d > 0 ? kBlock / d : 1;
+  const int threads = slots * d;
+  const int rows_pb = slots * kLstmRowsPerThread;
+  const int64_t blocks = (n + rows_pb - 1) / rows_pb;
+  if (blocks > INT32_MAX) return fail(SAGNN_ERR_ARG, "grid too large");
+  const size_t lds = (size_t)rows_pb * 2 * d * sizeof(float);
+  hipLaunchKernelGGL(lstm_fwd_valu_kernel, dim3((unsigned)blocks), dim3(threads), lds, s, x, ld_n, n,
+                     t, d, W, b, forget_bias, drop, h, ld_h);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+int mhsa_mean_valu(const float* x, int64_t ld_n, int64_t n, int t, int d, int heads,
+                   const float* Wq, const float* bq, const float* Wk, const float* bk,
+                   const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s) {
+  int slots = kBlock / d > 0 ? kBlock / d : 1;
+  while (slots > 1 && (size_t)slots * 4 * t * d * sizeof(float) > 64 * 1024) slots >>= 1;
+  const size_t lds = (size_t)slots * 4 * t * d * sizeof(float);
+  if (lds > 160 * 1024) return fail(SAGNN_ERR_DIM, "t*d = %d too large for LDS", t * d);
+  int64_t blocks = (n + slots - 1) / slots;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(mhsa_mean_valu_kernel, dim3((unsigned)blocks), dim3(slots * d), lds, s, x, ld_n,
+                     n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+}  // namespace sagnn
+
+extern "C" int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t n, int t, int d,
+                                  const float* W, const float* b, float forget_bias,
+                                  const float* drop_scale, float* h, int64_t ld_h, void* stream) {
+  if (int rc = check_dims(n, t, d)) return rc;
+  if (!x || !W || !b || !h) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (ld_n < (int64_t)t * d || ld_h < (int64_t)t * d)
+    return sagnn::fail(SAGNN_ERR_ARG, "node stride smaller than t*d");
+  if (n == 0) return SAGNN_OK;
+  return sagnn::lstm_fwd_valu(x, ld_n, n, t, d, W, b, forget_bias, drop_scale, h, ld_h,
+                              static_cast<hipStream_t>(stream));
+}
+
+extern "C" int sagnn_layernorm_td_f32(const float* x, int64_t ld_n, int64_t n, int t, int d,
+                                      const float* gamma, const float* beta, float eps, float* y,
+                                      int64_t ld_y, void* stream) {
+  if (int rc = check_dims(n, t, d)) return rc;
+  if (!x || !gamma || !beta || !y) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (ld_n < (int64_t)t * d || ld_y < (int64_t)t * d)
+    return sagnn::fail(SAGNN_ERR_ARG, "node stride smaller than t*d");
+  if (n == 0) return SAGNN_OK;
+  const int64_t blocks = (n + 3) / 4;
+  if (blocks > INT32_MAX) return sagnn::fail(SAGNN_ERR_ARG, "grid too large");
+  hipLaunchKernelGGL(layernorm_td_kernel, dim3((unsigned)blocks), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), x, ld_n, n, t, d, gamma, beta, eps, y, ld_y);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t n, int t, int d, int heads,
+                                   const float* Wq, const float* bq, const float* Wk,
+                                   const float* bk, const float* Wv, const float* bv, float* out,
+                                   int64_t ld_out, void* stream) {
+  if (int rc = check_dims(n, t, d)) return rc;
+  if (heads < 1 || d % heads) return sagnn::fail(SAGNN_ERR_DIM, "heads = %d does not divide d = %d", heads, d);
+  if (!x || !Wq || !bq || !Wk || !bk || !Wv || !bv || !out)
+    return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (ld_n < (int64_t)t * d || ld_out < d) return sagnn::fail(SAGNN_ERR_ARG, "stride too small");
+  if (n == 0) return SAGNN_OK;
+  return sagnn::mhsa_mean_valu(x, ld_n, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out,
+                               static_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t sagnn_interval_fusion_workspace_bytes(int64_t n, int t, int d) {
+  if (n <= 0 || t <= 0 || d <= 0) return 0;
+  return (size_t)n * (size_t)t * (size_t)d * sizeof(float);  // h, normalised in place
+}
+
+extern "C" int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t n, int t, int d,
+                                         int heads, const float* lstm_W, const float* lstm_b,
+                                         float forget_bias, const float* ln_gamma,
+                                         const float* ln_beta, float ln_eps, const float* Wq,
+                                         const float* bq, const float* Wk, const float* bk,
+                                         const float* Wv, const float* bv, float* out,
+                                         int64_t ld_out, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+  if (int rc = check_dims(n, t, d)) return rc;
+  const size_t need = sagnn_interval_fusion_workspace_bytes(n, t, d);
+  if (n > 0 && (!workspace || workspace_bytes < need))
+    return sagnn::fail(SAGNN_ERR_WORKSPACE, "fusion workspace needs %zu bytes", need);
+  float* h = static_cast<float*>(workspace);
+  const int64_t ldw = (int64_t)t * d;
+  if (int rc = sagnn_lstm_fwd_f32(x, ld_n, n, t, d, lstm_W, lstm_b, forget_bias, nullptr, h, ldw, stream)) return rc;
+  if (int rc = sagnn_layernorm_td_f32(h, ldw, n, t, d, ln_gamma, ln_beta, ln_eps, h, ldw, stream)) return rc;
+  return sagnn_mhsa_mean_f32(h, ldw, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out, stream);
+}

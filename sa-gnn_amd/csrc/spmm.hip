@@ -1,0 +1,526 @@
+// Interval SpMM for gfx950: out = leaky(A·X) + residual, with the running add_n fused.
+//
+// Replaces the GatherV2 -> SegmentSum -> Pad -> GatherV2 -> Maximum chain of
+// Recommender.messagePropagate (reference model.py:80-92) plus the residual add and add_n of
+// model.py:124-127. The adjacency is a binary pattern (edge values are dropped by the
+// reference, model.py:84-86), so the kernel reads rowptr + colidx only.
+//
+// Mapping (wave64): a feature row of d floats is covered by LPR = d/4 lanes holding one float4
+// each, so one `global_load_dwordx4` wave-instruction gathers G = 64/LPR neighbour rows
+// (1 KiB at d = 64). Rows are processed in three degree classes:
+//   short  (deg <= short_thresh) one lane-group per row, G rows of the wave's row block at once,
+//          a single accumulator added in edge order;
+//   medium (<= long_thresh)      the whole wave on one row, G neighbours per instruction, UN
+//          instructions in flight, then a cross-group shuffle reduction;
+//   long   (> long_thresh)       pre-cut into chunks (plan), one wave per chunk writing a raw
+//          partial sum, then a fix-up wave per row adds the partials in chunk order.
+// Column indices are fetched coalesced (one per lane) and broadcast with ds_bpermute.
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;              // 4 waves
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kRowsPerWave = 16;         // row block per wavefront (rowptr slice fits one lane each)
+constexpr int kUnroll = 8;               // gather instructions in flight per wave
+
+struct Epilogue {
+  const float* residual;
+  int64_t ldr;
+  const float* acc_in;
+  int64_t ld_acc_in;
+  float* out;
+  int64_t ldo;
+  float* acc_out;
+  int64_t ld_acc_out;
+  float leaky;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) {
+  return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void add4(float4& a, const float4& b) {
+  a.x += b.x;
+  a.y += b.y;
+  a.z += b.z;
+  a.w += b.w;
+}
+
+// y = max(leaky*s, s) + residual ; out = y ; acc_out = acc_in + y.
+__device__ __forceinline__ void finish_row(const Epilogue& ep, int64_t row, int col, float4 s) {
+  float4 y;
+  y.x = fmaxf(ep.leaky * s.x, s.x);
+  y.y = fmaxf(ep.leaky * s.y, s.y);
+  y.z = fmaxf(ep.leaky * s.z, s.z);
+  y.w = fmaxf(ep.leaky * s.w, s.w);
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ep.residual) {
+    r = ld4(ep.residual + row * ep.ldr + col);
+    add4(y, r);
+  }
+  if (ep.out) st4(ep.out + row * ep.ldo + col, y);
+  if (ep.acc_out) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ep.acc_in) {
+      a = (ep.acc_in == ep.residual && ep.ld_acc_in == ep.ldr)
+              ? r
+              : ld4(ep.acc_in + row * ep.ld_acc_in + col);
+    }
+    add4(a, y);
+    st4(ep.acc_out + row * ep.ld_acc_out + col, a);
+  }
+}
+
+// Whole wave sums X[idx[e], :] for e in [e0, e1): G neighbour rows per load instruction.
+// IDENT: the "index" of edge e is e itself (fix-up pass over the partial-sum workspace).
+// Returns the total in every lane-group (cross-group xor reduction).
+template <int LPR, bool IDENT>
+__device__ __forceinline__ float4 wave_row_sum(const int32_t* __restrict__ colidx, int e0, int e1,
+                                               const float* __restrict__ X, int64_t ldx,
+                                               int lane, int grp, int col, bool lane_on) {
+  constexpr int G = kWave / LPR;
+  constexpr int STEP = G * kUnroll;  // divides 64 for every LPR in {8,16,32,64}
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  int idx_next = -1;
+  if (e0 + lane < e1) idx_next = IDENT ? (e0 + lane) : colidx[e0 + lane];
+  for (int e = e0; e < e1; e += kWave) {
+    const int idx = idx_next;
+    const int en = e + kWave;
+    idx_next = -1;
+    if (en + lane < e1) idx_next = IDENT ? (en + lane) : colidx[en + lane];
+    const int cnt = min(kWave, e1 - e);
+    for (int j = 0; j < cnt; j += STEP) {
+      float4 v[kUnroll];
+      int c[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) c[u] = __shfl(idx, j + u * G + grp);
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c[u] >= 0 && lane_on) v[u] = ld4(X + (int64_t)c[u] * ldx + col);
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) add4(acc, v[u]);
+    }
+  }
+#pragma unroll
+  for (int off = LPR; off < kWave; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off);
+    acc.y += __shfl_xor(acc.y, off);
+    acc.z += __shfl_xor(acc.z, off);
+    acc.w += __shfl_xor(acc.w, off);
+  }
+  return acc;
+}
+
+// One launch covers the long-row chunks (first `chunk_blocks` blocks, heaviest work first)
+// and the row blocks (remaining blocks).
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+    const float* __restrict__ X, int64_t ldx, int d, int64_t n_rows, int short_t, int long_t,
+    const int32_t* __restrict__ chunk_e0, const int32_t* __restrict__ chunk_e1, int64_t n_chunks,
+    int chunk_blocks, float* __restrict__ partial, Epilogue ep) {
+  constexpr int G = kWave / LPR;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int grp = lane / LPR;
+  const int sub = lane % LPR;
+  const int col = 4 * sub;
+  const bool lane_on = col < d;
+
+  if ((int)blockIdx.x < chunk_blocks) {
+    const int64_t ci = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (ci >= n_chunks) return;
+    const float4 s =
+        wave_row_sum<LPR, false>(colidx, chunk_e0[ci], chunk_e1[ci], X, ldx, lane, grp, col, lane_on);
+    if (grp == 0 && lane_on) st4(partial + ci * (int64_t)d + col, s);
+    return;
+  }
+
+  const int64_t row0 = ((int64_t)(blockIdx.x - chunk_blocks) * kWavesPerBlock + wave) * kRowsPerWave;
+  if (row0 >= n_rows) return;
+  const int nr = (int)min((int64_t)kRowsPerWave, n_rows - row0);
+  // lane l (l <= nr) holds rowptr[row0 + l]; lanes beyond replicate the last entry (degree 0).
+  const int rp = rowptr[row0 + min(lane, nr)];
+  const int deg_l = (lane < nr) ? (__shfl_down(rp, 1) - rp) : 0;
+  unsigned long long medium = __ballot(deg_l > short_t && deg_l <= long_t);
+
+  // ---- short rows: one lane-group per row, G rows per iteration -------------------------
+  // The column-index slice of the next iteration is requested before this iteration's
+  // gathers so the two dependent HBM round trips overlap.
+  int e0_n = __shfl(rp, grp);
+  int dg_n = __shfl(deg_l, grp);
+  int idx_n = -1;
+  if (dg_n <= short_t && sub < dg_n) idx_n = colidx[e0_n + sub];
+#pragma unroll 1
+  for (int it = 0; it < kRowsPerWave / G; ++it) {
+    const int lr = it * G + grp;
+    const int e0 = e0_n;
+    const int dg = dg_n;
+    int idx = idx_n;
+    const bool mine = (lr < nr) && (dg <= short_t);
+    const int my_deg = mine ? dg : 0;
+    if (it + 1 < kRowsPerWave / G) {
+      e0_n = __shfl(rp, lr + G);
+      dg_n = __shfl(deg_l, lr + G);
+      idx_n = -1;
+      if (dg_n <= short_t && sub < dg_n) idx_n = colidx[e0_n + sub];
+    }
+    int maxdeg = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int x = __builtin_amdgcn_readlane(deg_l, it * G + g);
+      maxdeg = max(maxdeg, x <= short_t ? x : 0);
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int eo = 0; eo < maxdeg; eo += LPR) {
+      if (eo > 0) {
+        const int k = eo + sub;
+        idx = (k < my_deg) ? colidx[e0 + k] : -1;
+      }
+      const int lim = min(LPR, maxdeg - eo);
+      for (int j = 0; j < lim; j += kUnroll) {
+        float4 v[kUnroll];
+        int c[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) c[u] = __shfl(idx, grp * LPR + j + u);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+          v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (c[u] >= 0 && lane_on) v[u] = ld4(X + (int64_t)c[u] * ldx + col);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) add4(acc, v[u]);
+      }
+    }
+    if (mine && lane_on) finish_row(ep, row0 + lr, col, acc);
+  }
+
+  // ---- medium rows: the whole wave per row ----------------------------------------------
+  while (medium) {
+    const int lr = __builtin_ctzll(medium);
+    medium &= medium - 1;
+    const int e0 = __builtin_amdgcn_readlane(rp, lr);
+    const int dg = __builtin_amdgcn_readlane(deg_l, lr);
+    const float4 s = wave_row_sum<LPR, false>(colidx, e0, e0 + dg, X, ldx, lane, grp, col, lane_on);
+    if (grp == 0 && lane_on) finish_row(ep, row0 + lr, col, s);
+  }
+}
+
+// Fix-up for long rows: add the partial sums of a row in chunk order, then the epilogue.
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(const int32_t* __restrict__ long_row,
+                                                           const int32_t* __restrict__ long_slot,
+                                                           int64_t n_long,
+                                                           const float* __restrict__ partial, int d,
+                                                           Epilogue ep) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int grp = lane / LPR;
+  const int col = 4 * (lane % LPR);
+  const bool lane_on = col < d;
+  const int64_t li = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (li >= n_long) return;
+  const float4 s = wave_row_sum<LPR, true>(nullptr, long_slot[li], long_slot[li + 1], partial, d,
+                                           lane, grp, col, lane_on);
+  if (grp == 0 && lane_on) finish_row(ep, long_row[li], col, s);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// Plan
+// ------------------------------------------------------------------------------------------
+struct sagnn_spmm_plan {
+  sagnn_spmm_plan_info info{};
+  const int32_t* d_rowptr = nullptr;
+  const int32_t* d_colidx = nullptr;
+  // host copies of the chunk metadata (kept for tests / introspection)
+  std::vector<int32_t> chunk_row, chunk_e0, chunk_e1;
+  std::vector<int32_t> long_row, long_slot;  // long_slot has n_long+1 entries
+  // device copies: one allocation [chunk_e0 | chunk_e1 | long_row | long_slot]
+  int32_t* d_meta = nullptr;
+  const int32_t *d_chunk_e0 = nullptr, *d_chunk_e1 = nullptr, *d_long_row = nullptr,
+                *d_long_slot = nullptr;
+};
+
+namespace {
+constexpr int kDefaultShort = 16;
+constexpr int kDefaultLong = 2048;
+constexpr int kDefaultChunk = 1024;
+
+int check_rowptr(const int32_t* rp, int64_t n_rows, int64_t nnz) {
+  if (rp[0] != 0) return sagnn::fail(SAGNN_ERR_CSR, "rowptr[0] = %d, expected 0", rp[0]);
+  for (int64_t r = 0; r < n_rows; ++r)
+    if (rp[r + 1] < rp[r])
+      return sagnn::fail(SAGNN_ERR_CSR, "rowptr decreases at row %lld", (long long)r);
+  if (rp[n_rows] != nnz)
+    return sagnn::fail(SAGNN_ERR_CSR, "rowptr[n_rows] = %d but nnz = %lld", rp[n_rows],
+                       (long long)nnz);
+  return SAGNN_OK;
+}
+}  // namespace
+
+extern "C" int sagnn_csr_check_host(const int32_t* h_rowptr, const int32_t* h_colidx,
+                                    int64_t n_rows, int64_t n_src, int64_t nnz) {
+  if (!h_rowptr || (nnz > 0 && !h_colidx)) return sagnn::fail(SAGNN_ERR_NULL, "null CSR array");
+  if (n_rows < 0 || n_src < 0 || nnz < 0 || nnz > INT32_MAX || n_rows >= INT32_MAX ||
+      n_src > INT32_MAX)
+    return sagnn::fail(SAGNN_ERR_ARG, "CSR sizes out of int32 range");
+  if (int rc = check_rowptr(h_rowptr, n_rows, nnz)) return rc;
+  for (int64_t e = 0; e < nnz; ++e)
+    if (h_colidx[e] < 0 || h_colidx[e] >= n_src)
+      return sagnn::fail(SAGNN_ERR_CSR, "colidx[%lld] = %d outside [0, %lld)", (long long)e,
+                         h_colidx[e], (long long)n_src);
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_spmm_plan_create(const int32_t* h_rowptr, const int32_t* d_rowptr,
+                                      const int32_t* d_colidx, int64_t n_rows, int64_t n_src,
+                                      int64_t nnz, const sagnn_spmm_tuning* tuning,
+                                      sagnn_spmm_plan** plan_out) {
+  if (!plan_out) return sagnn::fail(SAGNN_ERR_NULL, "plan_out is NULL");
+  *plan_out = nullptr;
+  if (!h_rowptr) return sagnn::fail(SAGNN_ERR_NULL, "h_rowptr is NULL");
+  if ((d_rowptr == nullptr) != (d_colidx == nullptr) && nnz > 0)
+    return sagnn::fail(SAGNN_ERR_NULL, "d_rowptr and d_colidx must both be given or both NULL");
+  if (n_rows < 0 || n_src < 0 || nnz < 0 || nnz > INT32_MAX || n_rows >= INT32_MAX ||
+      n_src > INT32_MAX)
+    return sagnn::fail(SAGNN_ERR_ARG, "CSR sizes out of int32 range");
+  if (int rc = check_rowptr(h_rowptr, n_rows, nnz)) return rc;
+
+  sagnn_spmm_plan* p = new (std::nothrow) sagnn_spmm_plan();
+  if (!p) return sagnn::fail(SAGNN_ERR_NOMEM, "out of host memory");
+  int short_t = tuning && tuning->short_thresh > 0 ? tuning->short_thresh : kDefaultShort;
+  int long_t = tuning && tuning->long_thresh > 0 ? tuning->long_thresh : kDefaultLong;
+  int chunk = tuning && tuning->chunk_edges > 0 ? tuning->chunk_edges : kDefaultChunk;
+  chunk = (chunk + kWave - 1) / kWave * kWave;
+  if (long_t < short_t) long_t = short_t;
+
+  int32_t max_deg = 0;
+  try {
+    p->long_slot.push_back(0);
+    for (int64_t r = 0; r < n_rows; ++r) {
+      const int32_t b = h_rowptr[r], e = h_rowptr[r + 1], deg = e - b;
+      max_deg = std::max(max_deg, deg);
+      if (deg <= long_t) continue;
+      // balanced cut: nck chunks of equal length (multiple of 64, <= chunk)
+      const int32_t nck = (deg + chunk - 1) / chunk;
+      int32_t len = (deg + nck - 1) / nck;
+      len = (len + kWave - 1) / kWave * kWave;
+      for (int32_t s = b; s < e; s += len) {
+        p->chunk_row.push_back((int32_t)r);
+        p->chunk_e0.push_back(s);
+        p->chunk_e1.push_back(std::min(e, s + len));
+      }
+      p->long_row.push_back((int32_t)r);
+      p->long_slot.push_back((int32_t)p->chunk_row.size());
+    }
+  } catch (const std::bad_alloc&) {
+    delete p;
+    return sagnn::fail(SAGNN_ERR_NOMEM, "out of host memory building chunk list");
+  }
+
+  p->info.n_rows = n_rows;
+  p->info.n_src = n_src;
+  p->info.nnz = nnz;
+  p->info.n_long_rows = (int64_t)p->long_row.size();
+  p->info.n_chunks = (int64_t)p->chunk_row.size();
+  p->info.short_thresh = short_t;
+  p->info.long_thresh = long_t;
+  p->info.chunk_edges = chunk;
+  p->info.max_degree = max_deg;
+  p->info.on_device = 0;
+  p->d_rowptr = d_rowptr;
+  p->d_colidx = d_colidx;
+
+  if (d_rowptr) {
+    const size_t nck = p->chunk_row.size(), nl = p->long_row.size();
+    if (nck > 0) {
+      const size_t words = 2 * nck + nl + (nl + 1);
+      hipError_t e = hipMalloc((void**)&p->d_meta, words * sizeof(int32_t));
+      if (e != hipSuccess) {
+        delete p;
+        return sagnn::hip_fail(e, "hipMalloc(plan metadata)");
+      }
+      std::vector<int32_t> host(words);
+      std::copy(p->chunk_e0.begin(), p->chunk_e0.end(), host.begin());
+      std::copy(p->chunk_e1.begin(), p->chunk_e1.end(), host.begin() + nck);
+      std::copy(p->long_row.begin(), p->long_row.end(), host.begin() + 2 * nck);
+      std::copy(p->long_slot.begin(), p->long_slot.end(), host.begin() + 2 * nck + nl);
+      e = hipMemcpy(p->d_meta, host.data(), words * sizeof(int32_t), hipMemcpyHostToDevice);
+      if (e != hipSuccess) {
+        (void)hipFree(p->d_meta);
+        delete p;
+        return sagnn::hip_fail(e, "hipMemcpy(plan metadata)");
+      }
+      p->d_chunk_e0 = p->d_meta;
+      p->d_chunk_e1 = p->d_meta + nck;
+      p->d_long_row = p->d_meta + 2 * nck;
+      p->d_long_slot = p->d_meta + 2 * nck + nl;
+    }
+    p->info.on_device = 1;
+  }
+  *plan_out = p;
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_spmm_plan_destroy(sagnn_spmm_plan* plan) {
+  if (!plan) return SAGNN_OK;
+  if (plan->d_meta) (void)hipFree(plan->d_meta);
+  delete plan;
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_spmm_plan_get_info(const sagnn_spmm_plan* plan, sagnn_spmm_plan_info* info) {
+  if (!plan || !info) return sagnn::fail(SAGNN_ERR_NULL, "plan/info is NULL");
+  *info = plan->info;
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_spmm_plan_copy_chunks(const sagnn_spmm_plan* plan, int32_t* rows,
+                                           int32_t* e_begin, int32_t* e_end, int64_t cap) {
+  if (!plan) return sagnn::fail(SAGNN_ERR_NULL, "plan is NULL");
+  const int64_t n = plan->info.n_chunks;
+  if (cap < n) return sagnn::fail(SAGNN_ERR_ARG, "cap %lld < n_chunks %lld", (long long)cap, (long long)n);
+  if (n > 0 && (!rows || !e_begin || !e_end)) return sagnn::fail(SAGNN_ERR_NULL, "null output array");
+  std::copy(plan->chunk_row.begin(), plan->chunk_row.end(), rows);
+  std::copy(plan->chunk_e0.begin(), plan->chunk_e0.end(), e_begin);
+  std::copy(plan->chunk_e1.begin(), plan->chunk_e1.end(), e_end);
+  return SAGNN_OK;
+}
+
+extern "C" size_t sagnn_spmm_workspace_bytes(const sagnn_spmm_plan* plan, int d) {
+  if (!plan || d <= 0) return 0;
+  return (size_t)plan->info.n_chunks * (size_t)d * sizeof(float);
+}
+
+// ------------------------------------------------------------------------------------------
+// Launch
+// ------------------------------------------------------------------------------------------
+namespace {
+
+template <int LPR>
+int launch_spmm(const sagnn_spmm_plan* p, const float* X, int64_t ldx, int d, const Epilogue& ep,
+                float* partial, hipStream_t stream) {
+  const int64_t n_rows = p->info.n_rows;
+  const int64_t n_chunks = p->info.n_chunks;
+  const int64_t chunk_blocks = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t rows_per_block = (int64_t)kWavesPerBlock * kRowsPerWave;
+  const int64_t row_blocks = (n_rows + rows_per_block - 1) / rows_per_block;
+  const int64_t blocks = chunk_blocks + row_blocks;
+  if (blocks > INT32_MAX) return sagnn::fail(SAGNN_ERR_ARG, "grid too large");
+  if (blocks > 0) {
+    hipLaunchKernelGGL(spmm_rows_kernel<LPR>, dim3((unsigned)blocks), dim3(kBlock), 0, stream,
+                       p->d_rowptr, p->d_colidx, X, ldx, d, n_rows, p->info.short_thresh,
+                       p->info.long_thresh, p->d_chunk_e0, p->d_chunk_e1, n_chunks,
+                       (int)chunk_blocks, partial, ep);
+    SAGNN_HIP_TRY(hipGetLastError());
+  }
+  const int64_t n_long = p->info.n_long_rows;
+  if (n_long > 0) {
+    const int64_t fb = (n_long + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(spmm_fixup_kernel<LPR>, dim3((unsigned)fb), dim3(kBlock), 0, stream,
+                       p->d_long_row, p->d_long_slot, n_long, partial, d, ep);
+    SAGNN_HIP_TRY(hipGetLastError());
+  }
+  return SAGNN_OK;
+}
+
+int check_mat(const char* name, const void* ptr, int64_t ld, int d, bool required) {
+  if (!ptr) return required ? sagnn::fail(SAGNN_ERR_NULL, "%s is NULL", name) : SAGNN_OK;
+  if (!sagnn::aligned16(ptr) || (ld & 3) != 0)
+    return sagnn::fail(SAGNN_ERR_ALIGN, "%s: pointer must be 16-byte aligned and ld a multiple of 4", name);
+  if (ld < d) return sagnn::fail(SAGNN_ERR_ARG, "%s: ld %lld < d %d", name, (long long)ld, d);
+  return SAGNN_OK;
+}
+
+}  // namespace
+
+extern "C" int sagnn_spmm_f32(const sagnn_spmm_plan* plan, const float* X, int64_t ldx, int d,
+                              const float* residual, int64_t ldr, float leaky, float* out,
+                              int64_t ldo, const float* acc_in, int64_t ld_acc_in, float* acc_out,
+                              int64_t ld_acc_out, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  if (!plan) return sagnn::fail(SAGNN_ERR_NULL, "plan is NULL");
+  if (!plan->info.on_device) return sagnn::fail(SAGNN_ERR_ARG, "plan was built host-only (no device CSR)");
+  if (d < 4 || d > 256 || (d & 3)) return sagnn::fail(SAGNN_ERR_DIM, "d = %d: need a multiple of 4 in [4, 256]", d);
+  if (!out && !acc_out) return sagnn::fail(SAGNN_ERR_NULL, "both out and acc_out are NULL");
+  if (int rc = check_mat("X", X, ldx, d, plan->info.nnz > 0)) return rc;
+  if (int rc = check_mat("residual", residual, ldr, d, false)) return rc;
+  if (int rc = check_mat("out", out, ldo, d, false)) return rc;
+  if (int rc = check_mat("acc_in", acc_in, ld_acc_in, d, false)) return rc;
+  if (int rc = check_mat("acc_out", acc_out, ld_acc_out, d, false)) return rc;
+  if ((out && out == X) || (acc_out && acc_out == X))
+    return sagnn::fail(SAGNN_ERR_ARG, "out/acc_out must not alias X");
+  const size_t need = sagnn_spmm_workspace_bytes(plan, d);
+  if (need > 0) {
+    if (!workspace || workspace_bytes < need)
+      return sagnn::fail(SAGNN_ERR_WORKSPACE, "workspace needs %zu bytes, got %zu", need,
+                         workspace ? workspace_bytes : (size_t)0);
+    if (!sagnn::aligned16(workspace)) return sagnn::fail(SAGNN_ERR_ALIGN, "workspace not 16-byte aligned");
+  }
+  if (plan->info.n_rows == 0) return SAGNN_OK;
+
+  Epilogue ep{residual, ldr, acc_in, ld_acc_in, out, ldo, acc_out, ld_acc_out, leaky};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* partial = static_cast<float*>(workspace);
+  switch (sagnn::lanes_per_row(d)) {
+    case 8: return launch_spmm<8>(plan, X, ldx, d, ep, partial, s);
+    case 16: return launch_spmm<16>(plan, X, ldx, d, ep, partial, s);
+    case 32: return launch_spmm<32>(plan, X, ldx, d, ep, partial, s);
+    default: return launch_spmm<64>(plan, X, ldx, d, ep, partial, s);
+  }
+}
+
+extern "C" int sagnn_gnn_interval_f32(const sagnn_spmm_plan* plan_user,
+                                      const sagnn_spmm_plan* plan_item, const float* u0,
+                                      int64_t ld_u0, const float* i0, int64_t ld_i0, int d,
+                                      int n_layers, float leaky, float* scratch_u, float* scratch_i,
+                                      float* user_out, int64_t ld_uo, float* item_out, int64_t ld_io,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  if (!plan_user || !plan_item) return sagnn::fail(SAGNN_ERR_NULL, "plan is NULL");
+  if (!u0 || !i0 || !user_out || !item_out) return sagnn::fail(SAGNN_ERR_NULL, "null embedding pointer");
+  if (n_layers < 1) return sagnn::fail(SAGNN_ERR_ARG, "n_layers = %d: need >= 1", n_layers);
+  const int64_t U = plan_user->info.n_rows, I = plan_item->info.n_rows;
+  if (plan_user->info.n_src != I || plan_item->info.n_src != U)
+    return sagnn::fail(SAGNN_ERR_ARG, "plans are not a transposed pair: user %lldx%lld, item %lldx%lld",
+                       (long long)U, (long long)plan_user->info.n_src, (long long)I,
+                       (long long)plan_item->info.n_src);
+  if (n_layers > 1 && (!scratch_u || !scratch_i))
+    return sagnn::fail(SAGNN_ERR_NULL, "scratch buffers required for n_layers > 1");
+  // e^l lives in cur; layer l writes e^{l+1} into the other half of the ping-pong scratch
+  // (skipped for the last layer, whose only consumer is the running sum).
+  const float* cu = u0;
+  int64_t lcu = ld_u0;
+  const float* ci = i0;
+  int64_t lci = ld_i0;
+  for (int l = 0; l < n_layers; ++l) {
+    const bool last = (l + 1 == n_layers);
+    float* nu = last ? nullptr : scratch_u + (int64_t)(l & 1) * U * d;
+    float* ni = last ? nullptr : scratch_i + (int64_t)(l & 1) * I * d;
+    // layer 0 seeds the running sum with e^0 (acc_in = residual); later layers add in place.
+    const float* au = (l == 0) ? cu : user_out;
+    const int64_t lau = (l == 0) ? lcu : ld_uo;
+    const float* ai = (l == 0) ? ci : item_out;
+    const int64_t lai = (l == 0) ? lci : ld_io;
+    if (int rc = sagnn_spmm_f32(plan_user, ci, lci, d, cu, lcu, leaky, nu, d, au, lau, user_out,
+                                ld_uo, workspace, workspace_bytes, stream))
+      return rc;
+    if (int rc = sagnn_spmm_f32(plan_item, cu, lcu, d, ci, lci, leaky, ni, d, ai, lai, item_out,
+                                ld_io, workspace, workspace_bytes, stream))
+      return rc;
+    cu = nu;
+    lcu = d;
+    ci = ni;
+    lci = d;
+  }
+  return SAGNN_OK;
+}

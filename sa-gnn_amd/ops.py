@@ -1,0 +1,245 @@
+"""Tensor-level wrappers over the C ABI (include/sagnn.h): PyTorch-ROCm tensors in, HIP kernels
+out. torch is used for device memory and streams only — no arithmetic happens in torch here."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import PlanInfo, Tuning, check
+
+SUPPORTED_D = tuple(range(4, 257, 4))
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: torch.Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _f32_rows(name: str, t: torch.Tensor | None, d: int, rows: int | None = None):
+    """Checks a [rows, d] fp32 device matrix view with unit inner stride; returns its row stride."""
+    if t is None:
+        return 0
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError(f"{name}: expected a float32 device tensor, got {t.dtype} on {t.device}")
+    if t.dim() != 2 or t.shape[1] != d or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected shape [rows, {d}] with unit inner stride, got "
+                         f"{tuple(t.shape)} strides {t.stride()}")
+    if rows is not None and t.shape[0] != rows:
+        raise ValueError(f"{name}: expected {rows} rows, got {t.shape[0]}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), d)
+
+
+class SpmmPlan:
+    """Degree-class plan for one CSR adjacency (sagnn_spmm_plan_*). Owns the device CSR copies.
+
+    rowptr / colidx: int32, numpy or torch (host or device). With device=None a host-only plan
+    is built (no GPU touched) for inspecting the chunking."""
+
+    def __init__(self, rowptr, colidx, n_rows: int, n_src: int, device=None,
+                 tuning: tuple[int, int, int] | None = None, validate: bool = True):
+        lib = _lib.load()
+        self._lib = lib
+        self._h = ctypes.c_void_p()
+        self.n_rows, self.n_src = int(n_rows), int(n_src)
+        rp_t = torch.as_tensor(rowptr)
+        ci_t = torch.as_tensor(colidx)
+        if rp_t.dtype != torch.int32 or ci_t.dtype != torch.int32:
+            raise TypeError("rowptr/colidx must be int32")
+        if rp_t.numel() != self.n_rows + 1:
+            raise ValueError(f"rowptr has {rp_t.numel()} entries, expected n_rows+1 = {self.n_rows + 1}")
+        self.nnz = int(ci_t.numel())
+        rp_h = rp_t.cpu().contiguous()
+        self._rowptr_host = rp_h.numpy()
+        if validate:
+            ci_h = ci_t.cpu().contiguous()
+            check(lib.sagnn_csr_check_host(rp_h.data_ptr(), ci_h.data_ptr(), self.n_rows, self.n_src,
+                                           self.nnz))
+        tun = None
+        if tuning is not None:
+            tun = Tuning(int(tuning[0]), int(tuning[1]), int(tuning[2]), 0)
+        if device is None:
+            self.rowptr = self.colidx = None
+            d_rp = d_ci = None
+        else:
+            self.rowptr = rp_t.to(device).contiguous()
+            self.colidx = ci_t.to(device).contiguous()
+            if self.colidx.numel() == 0:  # keep a valid pointer for the (unused) argument
+                self.colidx = torch.zeros(1, dtype=torch.int32, device=device)
+            d_rp, d_ci = self.rowptr.data_ptr(), self.colidx.data_ptr()
+        check(lib.sagnn_spmm_plan_create(rp_h.data_ptr(), d_rp, d_ci, self.n_rows, self.n_src,
+                                         self.nnz, ctypes.byref(tun) if tun else None,
+                                         ctypes.byref(self._h)))
+        info = PlanInfo()
+        check(lib.sagnn_spmm_plan_get_info(self._h, ctypes.byref(info)))
+        self.info = info
+        self.device = device
+        self._ws: dict[int, torch.Tensor] = {}
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._lib.sagnn_spmm_plan_destroy(h)
+            self._h = ctypes.c_void_p()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def chunks(self):
+        """(rows, e_begin, e_end) int32 arrays of the long-row chunk list."""
+        n = int(self.info.n_chunks)
+        rows = np.empty(n, np.int32)
+        e0 = np.empty(n, np.int32)
+        e1 = np.empty(n, np.int32)
+        check(self._lib.sagnn_spmm_plan_copy_chunks(self._h, rows.ctypes.data, e0.ctypes.data,
+                                                    e1.ctypes.data, n))
+        return rows, e0, e1
+
+    def workspace_bytes(self, d: int) -> int:
+        return int(self._lib.sagnn_spmm_workspace_bytes(self._h, int(d)))
+
+    def workspace(self, d: int) -> torch.Tensor | None:
+        need = self.workspace_bytes(d)
+        if need == 0:
+            return None
+        ws = self._ws.get(d)
+        if ws is None:
+            ws = torch.empty(need // 4, dtype=torch.float32, device=self.device)
+            self._ws[d] = ws
+        return ws
+
+
+def spmm(plan: SpmmPlan, x: torch.Tensor, leaky: float, residual: torch.Tensor | None = None,
+         out: torch.Tensor | None = None, acc_in: torch.Tensor | None = None,
+         acc_out: torch.Tensor | None = None, want_out: bool = True) -> torch.Tensor | None:
+    """y = max(leaky*(A·x), A·x) + residual;  out = y;  acc_out = acc_in + y  (sagnn_spmm_f32).
+
+    Replaces Recommender.messagePropagate (reference model.py:80-92) and, through
+    residual/acc_*, the adds of model.py:124-127. Returns `out` (allocated if want_out and not
+    given)."""
+    d = int(x.shape[1])
+    ldx = _f32_rows("x", x, d, plan.n_src)
+    if out is None and want_out:
+        out = torch.empty((plan.n_rows, d), dtype=torch.float32, device=x.device)
+    ldr = _f32_rows("residual", residual, d, plan.n_rows)
+    ldo = _f32_rows("out", out, d, plan.n_rows)
+    ldai = _f32_rows("acc_in", acc_in, d, plan.n_rows)
+    ldao = _f32_rows("acc_out", acc_out, d, plan.n_rows)
+    ws = plan.workspace(d)
+    check(plan._lib.sagnn_spmm_f32(plan.handle, _ptr(x), ldx, d, _ptr(residual), ldr, float(leaky),
+                                   _ptr(out), ldo, _ptr(acc_in), ldai, _ptr(acc_out), ldao,
+                                   _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream()))
+    return out
+
+
+def gnn_interval(plan_user: SpmmPlan, plan_item: SpmmPlan, u0: torch.Tensor, i0: torch.Tensor,
+                 n_layers: int, leaky: float, user_out: torch.Tensor, item_out: torch.Tensor,
+                 scratch_u: torch.Tensor | None = None, scratch_i: torch.Tensor | None = None):
+    """One interval of the GNN loop (reference model.py:118-129): sagnn_gnn_interval_f32.
+    user_out / item_out are [rows, d] views (any row stride, e.g. a column of an [N, T, d] slab)."""
+    d = int(u0.shape[1])
+    U, I = plan_user.n_rows, plan_item.n_rows
+    ld_u0 = _f32_rows("u0", u0, d, U)
+    ld_i0 = _f32_rows("i0", i0, d, I)
+    ld_uo = _f32_rows("user_out", user_out, d, U)
+    ld_io = _f32_rows("item_out", item_out, d, I)
+    if n_layers > 1:
+        if scratch_u is None:
+            scratch_u = torch.empty((2, U, d), dtype=torch.float32, device=u0.device)
+        if scratch_i is None:
+            scratch_i = torch.empty((2, I, d), dtype=torch.float32, device=u0.device)
+        for name, s, rows in (("scratch_u", scratch_u, U), ("scratch_i", scratch_i, I)):
+            if s.dtype != torch.float32 or not s.is_contiguous() or s.numel() < 2 * rows * d:
+                raise ValueError(f"{name}: need a contiguous float32 buffer of 2*{rows}*{d} elements")
+    wu, wi = plan_user.workspace(d), plan_item.workspace(d)
+    ws = wu if (wi is None or (wu is not None and wu.numel() >= wi.numel())) else wi
+    check(plan_user._lib.sagnn_gnn_interval_f32(
+        plan_user.handle, plan_item.handle, _ptr(u0), ld_u0, _ptr(i0), ld_i0, d, int(n_layers),
+        float(leaky), _ptr(scratch_u), _ptr(scratch_i), _ptr(user_out), ld_uo, _ptr(item_out), ld_io,
+        _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream()))
+    return user_out, item_out
+
+
+def _ntd(name: str, x: torch.Tensor):
+    if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 3:
+        raise TypeError(f"{name}: expected a float32 device tensor [n, t, d]")
+    n, t, d = x.shape
+    if x.stride(2) != 1 or x.stride(1) != d:
+        raise ValueError(f"{name}: the (t, d) block of each node must be contiguous")
+    return int(n), int(t), int(d), (int(x.stride(0)) if n > 1 else t * d)
+
+
+def _vec(name: str, v: torch.Tensor, numel: int):
+    if v.dtype != torch.float32 or not v.is_cuda or not v.is_contiguous() or v.numel() != numel:
+        raise ValueError(f"{name}: expected a contiguous float32 device tensor of {numel} elements")
+    return v.data_ptr()
+
+
+def lstm_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, forget_bias: float = 1.0,
+             drop_scale: torch.Tensor | None = None, out: torch.Tensor | None = None):
+    """BasicLSTMCell over T (reference model.py:135-146): sagnn_lstm_fwd_f32. x [n, t, d]."""
+    n, t, d, ld = _ntd("x", x)
+    if out is None:
+        out = torch.empty((n, t, d), dtype=torch.float32, device=x.device)
+    _, _, _, ldh = _ntd("out", out)
+    if drop_scale is not None and (not drop_scale.is_contiguous() or drop_scale.shape != x.shape):
+        raise ValueError("drop_scale must be contiguous [n, t, d]")
+    check(_lib.load().sagnn_lstm_fwd_f32(x.data_ptr(), ld, n, t, d, _vec("W", W, 8 * d * d),
+                                         _vec("b", b, 4 * d), float(forget_bias), _ptr(drop_scale),
+                                         out.data_ptr(), ldh, _stream()))
+    return out
+
+
+def layernorm_td(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-12,
+                 out: torch.Tensor | None = None):
+    """layer_norm over (t, d) per node (reference model.py:152-153): sagnn_layernorm_td_f32."""
+    n, t, d, ld = _ntd("x", x)
+    if out is None:
+        out = torch.empty((n, t, d), dtype=torch.float32, device=x.device)
+    _, _, _, ldy = _ntd("out", out)
+    check(_lib.load().sagnn_layernorm_td_f32(x.data_ptr(), ld, n, t, d, _vec("gamma", gamma, d),
+                                             _vec("beta", beta, d), float(eps), out.data_ptr(), ldy,
+                                             _stream()))
+    return out
+
+
+def mhsa_mean(x: torch.Tensor, Wq, bq, Wk, bk, Wv, bv, heads: int, out: torch.Tensor | None = None):
+    """MultiHeadSelfAttention + mean over T (reference Utils/attention.py:55-78, model.py:154-155):
+    sagnn_mhsa_mean_f32. x [n, t, d] -> [n, d]."""
+    n, t, d, ld = _ntd("x", x)
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    ldo = _f32_rows("out", out, d, n)
+    check(_lib.load().sagnn_mhsa_mean_f32(
+        x.data_ptr(), ld, n, t, d, int(heads), _vec("Wq", Wq, d * d), _vec("bq", bq, d),
+        _vec("Wk", Wk, d * d), _vec("bk", bk, d), _vec("Wv", Wv, d * d), _vec("bv", bv, d),
+        out.data_ptr(), ldo, _stream()))
+    return out
+
+
+def interval_fusion(x: torch.Tensor, p: dict, heads: int, out: torch.Tensor | None = None,
+                    workspace: torch.Tensor | None = None):
+    """LSTM -> layer_norm -> MHSA -> mean (reference model.py:135-155): sagnn_interval_fusion_f32.
+    p: lstm_W [2d,4d], lstm_b [4d], ln_gamma [d], ln_beta [d], Wq/bq/Wk/bk/Wv/bv."""
+    lib = _lib.load()
+    n, t, d, ld = _ntd("x", x)
+    if out is None:
+        out = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    ldo = _f32_rows("out", out, d, n)
+    need = int(lib.sagnn_interval_fusion_workspace_bytes(n, t, d))
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(max(need // 4, 1), dtype=torch.float32, device=x.device)
+    check(lib.sagnn_interval_fusion_f32(
+        x.data_ptr(), ld, n, t, d, int(heads), _vec("lstm_W", p["lstm_W"], 8 * d * d),
+        _vec("lstm_b", p["lstm_b"], 4 * d), 1.0, _vec("ln_gamma", p["ln_gamma"], d),
+        _vec("ln_beta", p["ln_beta"], d), 1e-12, _vec("Wq", p["Wq"], d * d), _vec("bq", p["bq"], d),
+        _vec("Wk", p["Wk"], d * d), _vec("bk", p["bk"], d), _vec("Wv", p["Wv"], d * d),
+        _vec("bv", p["bv"], d), out.data_ptr(), ldo, workspace.data_ptr(),
+        workspace.numel() * workspace.element_size(), _stream()))
+    return out

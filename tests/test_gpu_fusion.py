@@ -1,0 +1,78 @@
+"""GPU parity: interval fusion kernels (LSTM, layer-norm over (T, d), MHSA + mean) against the
+oracle. fp32, tolerance 1e-4 (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import selfgnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-4, 2e-5
+
+
+def _params(d, rng, dev):
+    p = O.init_fusion_params(d, rng)
+    return p, {k: torch.from_numpy(v).to(dev) for k, v in p.items()}
+
+
+@pytest.mark.parametrize("d,t,n", [(64, 3, 1000), (32, 1, 77), (128, 6, 301), (64, 16, 130), (48, 5, 64), (256, 2, 33)])
+def test_lstm_vs_oracle(dev, d, t, n):
+    from sa_gnn_amd import ops
+    rng = np.random.default_rng(d * t)
+    x = rng.standard_normal((n, t, d)).astype(np.float32)
+    p, pd = _params(d, rng, dev)
+    got = ops.lstm_fwd(torch.from_numpy(x).to(dev), pd["lstm_W"], pd["lstm_b"], 1.0)
+    np.testing.assert_allclose(got.cpu().numpy(), O.basic_lstm(x, p["lstm_W"], p["lstm_b"], 1.0), rtol=RTOL, atol=ATOL)
+    scale = ((rng.random((n, t, d)) < 0.5) * 2.0).astype(np.float32)
+    got = ops.lstm_fwd(torch.from_numpy(x).to(dev), pd["lstm_W"], pd["lstm_b"], 1.0, drop_scale=torch.from_numpy(scale).to(dev))
+    np.testing.assert_allclose(got.cpu().numpy(), O.basic_lstm(x, p["lstm_W"], p["lstm_b"], 1.0, scale), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("d,t,n", [(64, 3, 513), (32, 1, 5), (128, 12, 70), (48, 5, 9)])
+def test_layernorm_vs_oracle(dev, d, t, n):
+    from sa_gnn_amd import ops
+    rng = np.random.default_rng(d + t)
+    x = (rng.standard_normal((n, t, d)) * 2 + 0.5).astype(np.float32)
+    p, pd = _params(d, rng, dev)
+    xd = torch.from_numpy(x).to(dev)
+    got = ops.layernorm_td(xd, pd["ln_gamma"], pd["ln_beta"])
+    want = O.layer_norm_td(x, p["ln_gamma"], p["ln_beta"])
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    ops.layernorm_td(xd, pd["ln_gamma"], pd["ln_beta"], out=xd)          # in place
+    np.testing.assert_allclose(xd.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("d,heads,t,n", [(64, 16, 3, 700), (32, 16, 1, 50), (128, 16, 6, 90), (64, 4, 16, 40), (64, 16, 12, 257)])
+def test_mhsa_mean_vs_oracle(dev, d, heads, t, n):
+    from sa_gnn_amd import ops
+    rng = np.random.default_rng(d + heads + t)
+    x = rng.standard_normal((n, t, d)).astype(np.float32)
+    p, pd = _params(d, rng, dev)
+    got = ops.mhsa_mean(torch.from_numpy(x).to(dev), pd["Wq"], pd["bq"], pd["Wk"], pd["bk"], pd["Wv"], pd["bv"], heads)
+    want = O.mhsa(x, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], heads).mean(axis=1)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("d,t,n", [(64, 3, 900), (128, 6, 200), (32, 1, 100), (64, 16, 300)])
+def test_interval_fusion_vs_oracle(dev, d, t, n):
+    from sa_gnn_amd import ops
+    rng = np.random.default_rng(d * 3 + t)
+    x = rng.standard_normal((n, t, d)).astype(np.float32)
+    p, pd = _params(d, rng, dev)
+    got = ops.interval_fusion(torch.from_numpy(x).to(dev), pd, 16)
+    np.testing.assert_allclose(got.cpu().numpy(), O.interval_fusion(x, p, 16), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("d", [32, 64, 128])
+def test_fusion_golden(dev, d):
+    from sa_gnn_amd import ops
+    g = np.load(os.path.join(GOLDEN, "oracle_tiny.npz"))
+    pd = {k.split("/")[-1]: torch.from_numpy(g[k]).to(dev) for k in g.files if k.startswith(f"d{d}/p/")}
+    uv = torch.from_numpy(g[f"d{d}/user_vector"]).to(dev)
+    np.testing.assert_allclose(ops.lstm_fwd(uv, pd["lstm_W"], pd["lstm_b"]).cpu().numpy(), g[f"d{d}/lstm_user"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(ops.interval_fusion(uv, pd, 16).cpu().numpy(), g[f"d{d}/final_user"], rtol=RTOL, atol=ATOL)
+    iv = torch.from_numpy(g[f"d{d}/item_vector"]).to(dev)
+    np.testing.assert_allclose(ops.interval_fusion(iv, pd, 16).cpu().numpy(), g[f"d{d}/final_item"], rtol=RTOL, atol=ATOL)

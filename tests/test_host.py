@@ -1,0 +1,164 @@
+"""CPU suite, part 2: the C-ABI library loads and exports every symbol include/sagnn.h declares,
+the host-side logic behind it (plan chunking, CSR validation, argument errors) and the Python
+host mirror (Params, DataHandler contract, synthetic writer). No GPU compute is called."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import ROOT
+from sa_gnn_amd import _lib
+from sa_gnn_amd.ops import SpmmPlan
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "sagnn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sagnn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol():
+    lib = _lib.load()
+    names = _header_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in sagnn.h but not exported by libsagnn.so"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES table out of sync with sagnn.h"
+    assert lib.sagnn_version() == 10100
+
+
+def test_csr_check_errors():
+    lib = _lib.load()
+    rp = np.array([0, 2, 2, 3], np.int32)
+    ci = np.array([1, 0, 2], np.int32)
+    assert lib.sagnn_csr_check_host(rp.ctypes.data, ci.ctypes.data, 3, 3, 3) == 0
+    bad = np.array([1, 0, 3], np.int32)
+    assert lib.sagnn_csr_check_host(rp.ctypes.data, bad.ctypes.data, 3, 3, 3) == -4
+    assert "colidx" in _lib.last_error()
+    dec = np.array([0, 2, 1, 3], np.int32)
+    assert lib.sagnn_csr_check_host(dec.ctypes.data, ci.ctypes.data, 3, 3, 3) == -4
+    assert lib.sagnn_csr_check_host(rp.ctypes.data, ci.ctypes.data, 3, 3, 4) == -4
+    assert lib.sagnn_csr_check_host(None, ci.ctypes.data, 3, 3, 3) == -1
+    with pytest.raises(_lib.SagnnError):
+        SpmmPlan(rp, bad, 3, 3)
+
+
+def test_plan_chunking_host_only():
+    """Long rows are cut into equal chunks (multiples of 64, <= chunk_edges), consecutive and in
+    edge order; short/medium rows need no metadata."""
+    rng = np.random.default_rng(0)
+    deg = rng.integers(0, 40, size=500)
+    deg[7] = 5000
+    deg[123] = 2049
+    deg[499] = 130000
+    deg[300] = 2048          # == long_thresh: stays a medium row
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
+    colidx = np.zeros(rowptr[-1], np.int32)
+    plan = SpmmPlan(rowptr, colidx, 500, 1)
+    info = plan.info
+    assert (info.short_thresh, info.long_thresh, info.chunk_edges) == (16, 2048, 1024)
+    assert info.on_device == 0 and info.max_degree == 130000
+    assert info.n_long_rows == 3
+    rows, e0, e1 = plan.chunks()
+    assert len(rows) == info.n_chunks
+    for r in (7, 123, 499):
+        sel = rows == r
+        b, e = e0[sel], e1[sel]
+        assert b[0] == rowptr[r] and e[-1] == rowptr[r + 1]
+        np.testing.assert_array_equal(b[1:], e[:-1])
+        lens = e - b
+        assert lens.max() <= 1024 and np.all(lens[:-1] % 64 == 0) and np.all(lens[:-1] == lens[0])
+        assert len(b) == -(-deg[r] // 1024)
+    assert 300 not in rows
+    assert plan.workspace_bytes(64) == info.n_chunks * 64 * 4
+    # custom tuning: everything above 8 edges is "long", 64-edge chunks
+    plan2 = SpmmPlan(rowptr, colidx, 500, 1, tuning=(4, 8, 64))
+    assert plan2.info.n_long_rows == int((deg > 8).sum())
+    r2, b2, e2 = plan2.chunks()
+    assert np.all(e2 - b2 <= 64)
+    # spmm on a host-only plan is refused, not silently skipped
+    lib = _lib.load()
+    rc = lib.sagnn_spmm_f32(plan.handle, None, 0, 64, None, 0, 0.5, None, 0, None, 0, None, 0, None, 0, None)
+    assert rc == -5 and "host-only" in _lib.last_error()
+
+
+def test_plan_rejects_bad_rowptr():
+    with pytest.raises(_lib.SagnnError):
+        SpmmPlan(np.array([0, 3, 2], np.int32), np.zeros(2, np.int32), 2, 4, validate=False)
+    with pytest.raises(ValueError):
+        SpmmPlan(np.array([0, 1], np.int32), np.zeros(1, np.int32), 2, 4)
+    with pytest.raises(TypeError):
+        SpmmPlan(np.array([0, 1, 1], np.int64), np.zeros(1, np.int32), 2, 4)
+
+
+def test_fusion_argument_errors_without_gpu():
+    lib = _lib.load()
+    assert lib.sagnn_lstm_fwd_f32(None, 0, 4, 2, 64, None, None, 1.0, None, None, 0, None) == -1
+    assert lib.sagnn_lstm_fwd_f32(None, 0, 4, 2, 62, None, None, 1.0, None, None, 0, None) == -2
+    assert lib.sagnn_mhsa_mean_f32(None, 0, 4, 2, 64, 7, None, None, None, None, None, None, None, 0, None) == -2
+    assert lib.sagnn_interval_fusion_workspace_bytes(10, 3, 64) == 10 * 3 * 64 * 4
+    assert lib.sagnn_layernorm_td_f32(None, 0, 0, 0, 64, None, None, 1e-12, None, 0, None) == -2
+
+
+def test_params_match_reference_flags():
+    from sa_gnn_amd import Params
+    a = Params.parse_args([])
+    # names/defaults of reference Params.py:5-50 used by the path
+    assert (a.graphNum, a.gnn_layer, a.latdim, a.leaky, a.keepRate, a.num_attention_heads) == (8, 2, 64, 0.5, 0.5, 16)
+    assert (a.batch, a.trnNum, a.decay_step, a.data, a.pos_length, a.att_layer) == (512, 10000, 19, "yelp", 200, 4)
+    # the reference's shell lines parse unchanged (gowalla.sh / amazon.sh)
+    g = Params.parse_args("--data gowalla --lr 2e-3 --reg 1e-2 --temp 0.1 --ssl_reg 1e-6 --save_path gowalla "
+                          "--epoch 150 --batch 512 --sslNum 40 --graphNum 3 --gnn_layer 2 --att_layer 1 "
+                          "--test True --testSize 1000 --ssldim 48".split())
+    assert (g.graphNum, g.gnn_layer, g.data, g.test, g.ssldim) == (3, 2, "gowalla", True, 48)
+    assert Params.parse_args(["--test", "False"]).test is True     # type=bool quirk (Params.py:47-49)
+
+
+def test_synthetic_writer_and_datahandler_contract(tmp_path):
+    from sa_gnn_amd import synthetic
+    from sa_gnn_amd.DataHandler import DataHandler
+    from sa_gnn_amd.Params import args
+    tmt = synthetic.make_trn_mat_time(300, 200, [1500, 1200, 0], seed0=1000)
+    assert len(tmt) == 3 and len(tmt[1]) == 3
+    for s in tmt[1]:
+        assert sp.isspmatrix_csr(s) and s.dtype == np.intc and s.shape == (300, 200)
+    assert tmt[1][0].data.min() > 1_000_000_000          # values are Unix timestamps
+    assert tmt[1][2].nnz == 0
+    seq = synthetic.make_sequence(tmt)
+    assert len(seq) == 300 and sum(len(s) for s in seq) == sum(s.nnz for s in tmt[1])
+    h = DataHandler.from_memory(tmt, seq)
+    assert (args.user, args.item) == (300, 200) and h.maxTime == 1
+    assert h.trnMat.shape == (300, 200) and len(h.subMat) == 3
+    # same objects through the reference's pickle files
+    import pickle
+    d = tmp_path / "synth"
+    d.mkdir()
+    for name, obj in (("trn_mat_time", tmt), ("sequence", seq), ("tst_int", [None] * 299 + [5])):
+        with open(d / name, "wb") as f:
+            pickle.dump(obj, f)
+    args.data = "synth"
+    h2 = DataHandler(root=str(tmp_path))
+    h2.LoadData()
+    assert list(h2.tstUsrs) == [299] and (h2.subMat[0] != tmt[1][0]).nnz == 0
+    args.data = "yelp"
+
+
+def test_powerlaw_generator_properties():
+    from sa_gnn_amd import synthetic
+    u, i = synthetic.powerlaw_edges(20000, 10000, 200000, seed=1000)
+    key = u * 10000 + i
+    assert u.numel() <= 200000 and u.numel() > 150000
+    assert torch.all(key[1:] > key[:-1])                 # sorted by (user, item), unique
+    (rp_u, ci_u), (rp_i, ci_i) = synthetic.csr_pair_from_edges(u, i, 20000, 10000)
+    assert rp_u[-1] == u.numel() == rp_i[-1]
+    a = sp.csr_matrix((np.ones(u.numel()), ci_u.numpy(), rp_u.numpy()), shape=(20000, 10000))
+    b = sp.csr_matrix((np.ones(u.numel()), ci_i.numpy(), rp_i.numpy()), shape=(10000, 20000))
+    assert (a - b.T).nnz == 0
+    du, di = np.diff(rp_u.numpy()), np.diff(rp_i.numpy())
+    assert du.max() > 20 * du.mean() / 4 and di.max() > 30 * di.mean()      # heavy tails
+    u2, i2 = synthetic.powerlaw_edges(20000, 10000, 200000, seed=1000)
+    assert torch.equal(u, u2) and torch.equal(i, i2)     # deterministic in the seed
