@@ -149,7 +149,10 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
   const int nr = (int)min((int64_t)kRowsPerWave, n_rows - row0);
   // lane l (l <= nr) holds rowptr[row0 + l]; lanes beyond replicate the last entry (degree 0).
   const int rp = rowptr[row0 + min(lane, nr)];
-  const int deg_l = (lane < nr) ? (__shfl_down(rp, 1) - rp) : 0;
+  // the shuffle must run with every lane active: a lane masked off by the select below would
+  // read 0 from ds_bpermute instead of its neighbour's rowptr entry
+  const int rp_up = __shfl_down(rp, 1);
+  const int deg_l = (lane < nr) ? (rp_up - rp) : 0;
   unsigned long long medium = __ballot(deg_l > short_t && deg_l <= long_t);
 
   // ---- short rows: one lane-group per row, G rows per iteration -------------------------

@@ -85,7 +85,7 @@ class SpmmPlan:
         h = getattr(self, "_h", None)
         if h is not None and h.value:
             self._lib.sagnn_spmm_plan_destroy(h)
-            self._h = ctypes.c_void_p()
+            self._h = None
 
     @property
     def handle(self):

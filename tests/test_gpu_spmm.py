@@ -15,6 +15,17 @@ pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-4, 1e-5
 
 
+def assert_sum_close(got, want, abs_terms):
+    """|got - want| <= 1e-4*|want| + 1e-5 + 3*eps32*sum|terms|: the relative bar of north_star plus
+    the fp32 forward-error allowance for an element that cancels to ~0 out of large terms (the
+    kernel and the oracle add the same terms in different orders)."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    tol = RTOL * np.abs(want) + ATOL + 2e-7 * np.asarray(abs_terms, np.float64)
+    bad = np.abs(got - want) > tol
+    assert not bad.any(), (f"{bad.sum()} / {bad.size} elements outside tolerance; worst "
+                           f"{np.abs(got - want)[bad].max():.3e} vs tol {tol[bad].min():.3e}")
+
+
 def _graph(rng, n_rows, n_src, degs):
     cols = [np.sort(rng.choice(n_src, size=int(dg), replace=False)) if dg <= n_src else
             rng.integers(0, n_src, size=int(dg)) for dg in degs]
@@ -53,14 +64,15 @@ def test_spmm_degree_classes(dev, d):
         if tuning is not None:
             assert plan.info.n_long_rows > 0
         want_y, want_acc = _oracle(idx, x, n_rows, 0.5, res, acc0)
+        terms, _ = _oracle(idx, np.abs(x), n_rows, 1.0)
         acc = torch.empty_like(rd)
         y = ops.spmm(plan, xd, 0.5, residual=rd, acc_in=ad, acc_out=acc)
-        np.testing.assert_allclose(y.cpu().numpy(), want_y, rtol=RTOL, atol=ATOL)
-        np.testing.assert_allclose(acc.cpu().numpy(), want_acc, rtol=RTOL, atol=ATOL)
+        assert_sum_close(y.cpu().numpy(), want_y, terms)
+        assert_sum_close(acc.cpu().numpy(), want_acc, terms)
         # plain form: no residual, no accumulator; isolated rows are exactly zero
         y2 = ops.spmm(plan, xd, 0.1)
         w2, _ = _oracle(idx, x, n_rows, 0.1)
-        np.testing.assert_allclose(y2.cpu().numpy(), w2, rtol=RTOL, atol=ATOL)
+        assert_sum_close(y2.cpu().numpy(), w2, terms)
         assert torch.all(y2[[0, 1, 2, 100, 775]] == 0)
 
 
@@ -129,13 +141,15 @@ def test_gnn_interval_vs_oracle(dev, d, L):
     fwd, tp = graph.interval_pair(m, dev, tuning=(8, 16, 64))
     u0 = rng.standard_normal((U, d)).astype(np.float32)
     i0 = rng.standard_normal((I, d)).astype(np.float32)
-    want_u, want_i = O.gnn_interval(u0, i0, O.trans_to_lsts(m)[0], O.trans_to_lsts(O.transpose(m))[0], L, 0.5)
+    adj_idx, tp_idx = O.trans_to_lsts(m)[0], O.trans_to_lsts(O.transpose(m))[0]
+    want_u, want_i = O.gnn_interval(u0, i0, adj_idx, tp_idx, L, 0.5)
+    terms_u, terms_i = O.gnn_interval(np.abs(u0), np.abs(i0), adj_idx, tp_idx, L, 1.0)
     us = torch.zeros((U, T, d), device=dev)
     its = torch.zeros((I, T, d), device=dev)
     ops.gnn_interval(fwd.plan, tp.plan, torch.from_numpy(u0).to(dev), torch.from_numpy(i0).to(dev), L, 0.5,
                      us[:, 1, :], its[:, 1, :])
-    np.testing.assert_allclose(us[:, 1].cpu().numpy(), want_u, rtol=RTOL, atol=ATOL)
-    np.testing.assert_allclose(its[:, 1].cpu().numpy(), want_i, rtol=RTOL, atol=ATOL)
+    assert_sum_close(us[:, 1].cpu().numpy(), want_u, terms_u)
+    assert_sum_close(its[:, 1].cpu().numpy(), want_i, terms_i)
     assert torch.all(us[:, 0] == 0) and torch.all(us[:, 2] == 0)
 
 
