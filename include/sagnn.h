@@ -52,6 +52,19 @@ int sagnn_version(void);
 size_t sagnn_last_error(char* buf, size_t cap);
 
 /* ------------------------------------------------------------------------------------
+ * Per-launch timing with HIP events recorded on the launch stream (bench.py's roofline
+ * figure). sagnn_profile_enable(capacity) pre-creates `capacity` event pairs and turns
+ * recording on (capacity 0 turns it off and frees them); every kernel launch the library
+ * issues then takes one slot until they run out. sagnn_profile_read synchronises on the
+ * recorded events, returns up to `cap` records in issue order and clears the log.
+ * kind: 0 = SpMM row/chunk kernel (units_a = nnz, units_b = n_rows), 1 = SpMM fix-up,
+ *       2 = LSTM, 3 = layer-norm, 4 = MHSA+mean (units_a = n, units_b = t).
+ * -------------------------------------------------------------------------------- */
+int sagnn_profile_enable(int capacity);
+int sagnn_profile_read(float* ms, int32_t* kind, int64_t* units_a, int64_t* units_b, int cap,
+                       int* n_out);
+
+/* ------------------------------------------------------------------------------------
  * CSR validation (host). Replaces nothing in the reference: TF-CPU raised
  * InvalidArgument from GatherV2 on an out-of-range index (model.py:86); the kernels do
  * not bounds-check, so the host wrapper calls this once per adjacency at load time.
@@ -149,8 +162,11 @@ int sagnn_gnn_interval_f32(const sagnn_spmm_plan* plan_user, const sagnn_spmm_pl
                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * Interval fusion (model.py:135-155). x is [n, t, d] with row stride ld_n (elements)
- * between nodes and d between intervals.
+ * Interval fusion (model.py:135-155). x[node, interval, :] is read at
+ * x + node*ld_n + interval*ld_t (elements): [n, t, d] storage is ld_t = d, ld_n >= t*d (what
+ * tf.stack + tf.transpose produce, model.py:131-134); [t, n, d] storage is ld_n = d,
+ * ld_t >= n*d (what the interval-sharded exchange delivers). Outputs h / y are [n, t, d] with
+ * node stride ld_h / ld_y and the t*d block of a node dense.
  *
  * sagnn_lstm_fwd_f32 — dynamic_rnn(MultiRNNCell([DropoutWrapper(BasicLSTMCell(d))]))
  *   (model.py:135-146) at keep probability 1: TF 1.14 BasicLSTMCell, kernel W [2d, 4d]
@@ -173,17 +189,17 @@ int sagnn_gnn_interval_f32(const sagnn_spmm_plan* plan_user, const sagnn_spmm_pl
  *   output kept in a caller-provided workspace (sagnn_interval_fusion_workspace_bytes) and
  *   normalised in place; only out [n, d] is a result.
  * -------------------------------------------------------------------------------- */
-int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t n, int t, int d, const float* W,
+int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
                        const float* b, float forget_bias, const float* drop_scale, float* h,
                        int64_t ld_h, void* stream);
-int sagnn_layernorm_td_f32(const float* x, int64_t ld_n, int64_t n, int t, int d,
+int sagnn_layernorm_td_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
                            const float* gamma, const float* beta, float eps, float* y,
                            int64_t ld_y, void* stream);
-int sagnn_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t n, int t, int d, int heads,
+int sagnn_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
                         const float* Wq, const float* bq, const float* Wk, const float* bk,
                         const float* Wv, const float* bv, float* out, int64_t ld_out,
                         void* stream);
-int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t n, int t, int d, int heads,
+int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
                               const float* lstm_W, const float* lstm_b, float forget_bias,
                               const float* ln_gamma, const float* ln_beta, float ln_eps,
                               const float* Wq, const float* bq, const float* Wk, const float* bk,

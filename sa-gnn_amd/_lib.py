@@ -32,6 +32,8 @@ class PlanInfo(ctypes.Structure):
 SIGNATURES = {
     "sagnn_version": (c_int, []),
     "sagnn_last_error": (c_size_t, [c_char_p, c_size_t]),
+    "sagnn_profile_enable": (c_int, [c_int]),
+    "sagnn_profile_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, POINTER(c_int)]),
     "sagnn_csr_check_host": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64]),
     "sagnn_spmm_plan_create": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                        POINTER(Tuning), POINTER(c_void_p)]),
@@ -45,14 +47,14 @@ SIGNATURES = {
     "sagnn_gnn_interval_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                        c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
-    "sagnn_lstm_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,
+    "sagnn_lstm_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,
                                    c_float, c_void_p, c_void_p, c_int64, c_void_p]),
-    "sagnn_layernorm_td_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,
+    "sagnn_layernorm_td_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,
                                        c_float, c_void_p, c_int64, c_void_p]),
-    "sagnn_mhsa_mean_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p,
+    "sagnn_mhsa_mean_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int64, c_void_p]),
-    "sagnn_interval_fusion_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p,
+    "sagnn_interval_fusion_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p,
                                           c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                           c_int64, c_void_p, c_size_t, c_void_p]),

@@ -4,6 +4,9 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <mutex>
+#include <vector>
+
 namespace sagnn {
 
 std::string& last_error_slot() {
@@ -28,7 +31,83 @@ int hip_fail(hipError_t e, const char* what) {
   return (int)e;
 }
 
+// ---- profiler ---------------------------------------------------------------------------------
+namespace {
+struct ProfRecord {
+  hipEvent_t start, stop;
+  int kind;
+  int64_t a, b;
+};
+struct Profiler {
+  std::mutex mu;
+  std::vector<ProfRecord> rec;  // pre-created events
+  int used = 0;
+  bool enabled = false;
+};
+Profiler& profiler() {
+  static Profiler p;
+  return p;
+}
+}  // namespace
+
+ProfileScope::ProfileScope(int kind, hipStream_t stream, int64_t a, int64_t b) : slot_(-1), stream_(stream) {
+  Profiler& p = profiler();
+  if (!p.enabled) return;
+  std::lock_guard<std::mutex> lock(p.mu);
+  if (!p.enabled || p.used >= (int)p.rec.size()) return;
+  slot_ = p.used++;
+  p.rec[slot_].kind = kind;
+  p.rec[slot_].a = a;
+  p.rec[slot_].b = b;
+  (void)hipEventRecord(p.rec[slot_].start, stream_);
+}
+
+ProfileScope::~ProfileScope() {
+  if (slot_ < 0) return;
+  (void)hipEventRecord(profiler().rec[slot_].stop, stream_);
+}
+
 }  // namespace sagnn
+
+extern "C" int sagnn_profile_enable(int capacity) {
+  auto& p = sagnn::profiler();
+  std::lock_guard<std::mutex> lock(p.mu);
+  for (auto& r : p.rec) {
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  p.rec.clear();
+  p.used = 0;
+  p.enabled = false;
+  if (capacity <= 0) return SAGNN_OK;
+  p.rec.resize(capacity);
+  for (auto& r : p.rec) {
+    SAGNN_HIP_TRY(hipEventCreate(&r.start));
+    SAGNN_HIP_TRY(hipEventCreate(&r.stop));
+  }
+  p.enabled = true;
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_profile_read(float* ms, int32_t* kind, int64_t* units_a, int64_t* units_b,
+                                  int cap, int* n_out) {
+  auto& p = sagnn::profiler();
+  std::lock_guard<std::mutex> lock(p.mu);
+  if (!n_out) return sagnn::fail(SAGNN_ERR_NULL, "n_out is NULL");
+  const int n = p.used < cap ? p.used : cap;
+  for (int i = 0; i < n; ++i) {
+    SAGNN_HIP_TRY(hipEventSynchronize(p.rec[i].stop));
+    float t = 0.f;
+    SAGNN_HIP_TRY(hipEventElapsedTime(&t, p.rec[i].start, p.rec[i].stop));
+    if (ms) ms[i] = t;
+    if (kind) kind[i] = p.rec[i].kind;
+    if (units_a) units_a[i] = p.rec[i].a;
+    if (units_b) units_b[i] = p.rec[i].b;
+  }
+  *n_out = n;
+  p.used = 0;
+  return SAGNN_OK;
+}
 
 extern "C" int sagnn_version(void) { return SAGNN_VERSION; }
 

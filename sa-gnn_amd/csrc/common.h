@@ -30,4 +30,21 @@ inline int lanes_per_row(int d) {
   return lpr;  // 8, 16, 32 or 64 for d <= 256
 }
 
+// ---- optional per-launch timing (sagnn_profile_*) -------------------------------------------
+enum ProfileKind { kProfSpmmRows = 0, kProfSpmmFixup = 1, kProfLstm = 2, kProfLayerNorm = 3, kProfMhsa = 4 };
+
+// Records a hipEvent pair around the launches issued during its lifetime, on the launch stream,
+// when profiling is enabled; otherwise does nothing.
+class ProfileScope {
+ public:
+  ProfileScope(int kind, hipStream_t stream, int64_t units_a, int64_t units_b);
+  ~ProfileScope();
+  ProfileScope(const ProfileScope&) = delete;
+  ProfileScope& operator=(const ProfileScope&) = delete;
+
+ private:
+  int slot_;
+  hipStream_t stream_;
+};
+
 }  // namespace sagnn

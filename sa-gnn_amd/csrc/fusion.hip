@@ -17,8 +17,8 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 // TF 1.14 BasicLSTMCell.call (rnn_cell_impl.py): gate_inputs = [x, h] @ W + b;
 // i, j, f, o = split(gate_inputs, 4); c' = c*sigmoid(f + forget_bias) + sigmoid(i)*tanh(j);
 // h' = tanh(c')*sigmoid(o).
-__global__ void lstm_fwd_valu_kernel(const float* __restrict__ x, int64_t ld_n, int64_t n, int t,
-                                     int d, const float* __restrict__ W,
+__global__ void lstm_fwd_valu_kernel(const float* __restrict__ x, int64_t ld_n, int64_t ld_t,
+                                     int64_t n, int t, int d, const float* __restrict__ W,
                                      const float* __restrict__ b, float forget_bias,
                                      const float* __restrict__ drop, float* __restrict__ h_out,
                                      int64_t ld_h) {
@@ -41,7 +41,7 @@ __global__ void lstm_fwd_valu_kernel(const float* __restrict__ x, int64_t ld_n, 
     for (int i = threadIdx.x; i < rows_pb * d; i += blockDim.x) {
       const int r = i / d, k = i % d;
       const int64_t row = row_base + r;
-      sm[r * d2 + k] = row < n ? x[row * ld_n + (int64_t)ts * d + k] : 0.f;
+      sm[r * d2 + k] = row < n ? x[row * ld_n + (int64_t)ts * ld_t + k] : 0.f;
     }
     __syncthreads();
     float gi[RPT], gj[RPT], gf[RPT], go[RPT];
@@ -85,7 +85,7 @@ __global__ void lstm_fwd_valu_kernel(const float* __restrict__ x, int64_t ld_n, 
 // then tf.nn.batch_normalization: inv = rsqrt(var + eps) * gamma; y = x*inv + (beta - mean*inv).
 // One wavefront per node.
 // x and y may alias (in-place): each element is read and written by the same lane.
-__global__ void layernorm_td_kernel(const float* x, int64_t ld_n, int64_t n, int t, int d,
+__global__ void layernorm_td_kernel(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
                                     const float* __restrict__ gamma,
                                     const float* __restrict__ beta, float eps, float* y,
                                     int64_t ld_y) {
@@ -94,14 +94,15 @@ __global__ void layernorm_td_kernel(const float* x, int64_t ld_n, int64_t n, int
   if (node >= n) return;
   const int td = t * d;
   const float* xr = x + node * ld_n;
+  // element i = (ts, k) of the node sits at ts*ld_t + k in x and at i in the dense output
   float s = 0.f;
-  for (int i = lane; i < td; i += 64) s += xr[i];
+  for (int i = lane; i < td; i += 64) s += xr[(int64_t)(i / d) * ld_t + (i % d)];
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
   const float mean = s / (float)td;
   float v = 0.f;
   for (int i = lane; i < td; i += 64) {
-    const float dlt = xr[i] - mean;
+    const float dlt = xr[(int64_t)(i / d) * ld_t + (i % d)] - mean;
     v = fmaf(dlt, dlt, v);
   }
 #pragma unroll
@@ -111,13 +112,14 @@ __global__ void layernorm_td_kernel(const float* x, int64_t ld_n, int64_t n, int
   for (int i = lane; i < td; i += 64) {
     const int k = i % d;
     const float inv = rstd * gamma[k];
-    yr[i] = xr[i] * inv + (beta[k] - mean * inv);
+    yr[i] = xr[(int64_t)(i / d) * ld_t + k] * inv + (beta[k] - mean * inv);
   }
 }
 
 // MultiHeadSelfAttention.attention + reduce_mean over the query axis. d threads per node.
-__global__ void mhsa_mean_valu_kernel(const float* __restrict__ x, int64_t ld_n, int64_t n, int t,
-                                      int d, int heads, const float* __restrict__ Wq,
+__global__ void mhsa_mean_valu_kernel(const float* __restrict__ x, int64_t ld_n, int64_t ld_t,
+                                      int64_t n, int t, int d, int heads,
+                                      const float* __restrict__ Wq,
                                       const float* __restrict__ bq, const float* __restrict__ Wk,
                                       const float* __restrict__ bk, const float* __restrict__ Wv,
                                       const float* __restrict__ bv, float* __restrict__ out,
@@ -138,7 +140,7 @@ __global__ void mhsa_mean_valu_kernel(const float* __restrict__ x, int64_t ld_n,
   for (int64_t node0 = (int64_t)blockIdx.x * slots; node0 < n; node0 += (int64_t)gridDim.x * slots) {
     const int64_t node = node0 + slot;
     const bool valid = node < n;
-    for (int ts = 0; ts < t; ++ts) ys[ts * d + j] = valid ? x[node * ld_n + (int64_t)ts * d + j] : 0.f;
+    for (int ts = 0; ts < t; ++ts) ys[ts * d + j] = valid ? x[node * ld_n + (int64_t)ts * ld_t + j] : 0.f;
     __syncthreads();
     for (int ts = 0; ts < t; ++ts) {
       float q = 0.f, k = 0.f, v = 0.f;
@@ -177,11 +179,23 @@ int check_dims(int64_t n, int t, int d) {
   return SAGNN_OK;
 }
 
+// x[node, ts, :] lives at node*ld_n + ts*ld_t: either [n, t, d] (ld_t = d, ld_n >= t*d) or
+// [t, n, d] (ld_n = d, ld_t >= n*d) or any other non-overlapping pair of strides.
+int check_strides(int64_t ld_n, int64_t ld_t, int64_t n, int t, int d) {
+  if (ld_n < d || ld_t < d) return sagnn::fail(SAGNN_ERR_ARG, "ld_n / ld_t smaller than d");
+  const bool node_major = ld_n >= (int64_t)(t - 1) * ld_t + d;
+  const bool time_major = ld_t >= (n - 1) * ld_n + d;
+  if (!node_major && !time_major && n > 1 && t > 1)
+    return sagnn::fail(SAGNN_ERR_ARG, "ld_n = %lld, ld_t = %lld overlap for n = %lld, t = %d",
+                       (long long)ld_n, (long long)ld_t, (long long)n, t);
+  return SAGNN_OK;
+}
+
 }  // namespace
 
 namespace sagnn {
 
-int lstm_fwd_valu(const float* x, int64_t ld_n, int64_t n, int t, int d, const float* W,
+int lstm_fwd_valu(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
                   const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
                   hipStream_t s) {
   const int slots = kBlock / d > 0 ? kBlock / d : 1;
@@ -190,13 +204,14 @@ int lstm_fwd_valu(const float* x, int64_t ld_n, int64_t n, int t, int d, const f
   const int64_t blocks = (n + rows_pb - 1) / rows_pb;
   if (blocks > INT32_MAX) return fail(SAGNN_ERR_ARG, "grid too large");
   const size_t lds = (size_t)rows_pb * 2 * d * sizeof(float);
-  hipLaunchKernelGGL(lstm_fwd_valu_kernel, dim3((unsigned)blocks), dim3(threads), lds, s, x, ld_n, n,
-                     t, d, W, b, forget_bias, drop, h, ld_h);
+  ProfileScope prof(kProfLstm, s, n, t);
+  hipLaunchKernelGGL(lstm_fwd_valu_kernel, dim3((unsigned)blocks), dim3(threads), lds, s, x, ld_n, ld_t,
+                     n, t, d, W, b, forget_bias, drop, h, ld_h);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
 
-int mhsa_mean_valu(const float* x, int64_t ld_n, int64_t n, int t, int d, int heads,
+int mhsa_mean_valu(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
                    const float* Wq, const float* bq, const float* Wk, const float* bk,
                    const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s) {
   int slots = kBlock / d > 0 ? kBlock / d : 1;
@@ -205,43 +220,45 @@ int mhsa_mean_valu(const float* x, int64_t ld_n, int64_t n, int t, int d, int he
   if (lds > 160 * 1024) return fail(SAGNN_ERR_DIM, "t*d = %d too large for LDS", t * d);
   int64_t blocks = (n + slots - 1) / slots;
   if (blocks > 8192) blocks = 8192;
+  ProfileScope prof(kProfMhsa, s, n, t);
   hipLaunchKernelGGL(mhsa_mean_valu_kernel, dim3((unsigned)blocks), dim3(slots * d), lds, s, x, ld_n,
-                     n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out);
+                     ld_t, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
 
 }  // namespace sagnn
 
-extern "C" int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t n, int t, int d,
+extern "C" int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
                                   const float* W, const float* b, float forget_bias,
                                   const float* drop_scale, float* h, int64_t ld_h, void* stream) {
   if (int rc = check_dims(n, t, d)) return rc;
   if (!x || !W || !b || !h) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
-  if (ld_n < (int64_t)t * d || ld_h < (int64_t)t * d)
-    return sagnn::fail(SAGNN_ERR_ARG, "node stride smaller than t*d");
+  if (int rc = check_strides(ld_n, ld_t, n, t, d)) return rc;
+  if (ld_h < (int64_t)t * d) return sagnn::fail(SAGNN_ERR_ARG, "ld_h smaller than t*d");
   if (n == 0) return SAGNN_OK;
-  return sagnn::lstm_fwd_valu(x, ld_n, n, t, d, W, b, forget_bias, drop_scale, h, ld_h,
+  return sagnn::lstm_fwd_valu(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h,
                               static_cast<hipStream_t>(stream));
 }
 
-extern "C" int sagnn_layernorm_td_f32(const float* x, int64_t ld_n, int64_t n, int t, int d,
+extern "C" int sagnn_layernorm_td_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
                                       const float* gamma, const float* beta, float eps, float* y,
                                       int64_t ld_y, void* stream) {
   if (int rc = check_dims(n, t, d)) return rc;
   if (!x || !gamma || !beta || !y) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
-  if (ld_n < (int64_t)t * d || ld_y < (int64_t)t * d)
-    return sagnn::fail(SAGNN_ERR_ARG, "node stride smaller than t*d");
+  if (int rc = check_strides(ld_n, ld_t, n, t, d)) return rc;
+  if (ld_y < (int64_t)t * d) return sagnn::fail(SAGNN_ERR_ARG, "ld_y smaller than t*d");
   if (n == 0) return SAGNN_OK;
   const int64_t blocks = (n + 3) / 4;
   if (blocks > INT32_MAX) return sagnn::fail(SAGNN_ERR_ARG, "grid too large");
+  sagnn::ProfileScope prof(sagnn::kProfLayerNorm, static_cast<hipStream_t>(stream), n, t);
   hipLaunchKernelGGL(layernorm_td_kernel, dim3((unsigned)blocks), dim3(kBlock), 0,
-                     static_cast<hipStream_t>(stream), x, ld_n, n, t, d, gamma, beta, eps, y, ld_y);
+                     static_cast<hipStream_t>(stream), x, ld_n, ld_t, n, t, d, gamma, beta, eps, y, ld_y);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
 
-extern "C" int sagnn_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t n, int t, int d, int heads,
+extern "C" int sagnn_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
                                    const float* Wq, const float* bq, const float* Wk,
                                    const float* bk, const float* Wv, const float* bv, float* out,
                                    int64_t ld_out, void* stream) {
@@ -249,9 +266,10 @@ extern "C" int sagnn_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t n, int 
   if (heads < 1 || d % heads) return sagnn::fail(SAGNN_ERR_DIM, "heads = %d does not divide d = %d", heads, d);
   if (!x || !Wq || !bq || !Wk || !bk || !Wv || !bv || !out)
     return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
-  if (ld_n < (int64_t)t * d || ld_out < d) return sagnn::fail(SAGNN_ERR_ARG, "stride too small");
+  if (int rc = check_strides(ld_n, ld_t, n, t, d)) return rc;
+  if (ld_out < d) return sagnn::fail(SAGNN_ERR_ARG, "ld_out smaller than d");
   if (n == 0) return SAGNN_OK;
-  return sagnn::mhsa_mean_valu(x, ld_n, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out,
+  return sagnn::mhsa_mean_valu(x, ld_n, ld_t, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out,
                                static_cast<hipStream_t>(stream));
 }
 
@@ -260,8 +278,8 @@ extern "C" size_t sagnn_interval_fusion_workspace_bytes(int64_t n, int t, int d)
   return (size_t)n * (size_t)t * (size_t)d * sizeof(float);  // h, normalised in place
 }
 
-extern "C" int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t n, int t, int d,
-                                         int heads, const float* lstm_W, const float* lstm_b,
+extern "C" int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t,
+                                         int d, int heads, const float* lstm_W, const float* lstm_b,
                                          float forget_bias, const float* ln_gamma,
                                          const float* ln_beta, float ln_eps, const float* Wq,
                                          const float* bq, const float* Wk, const float* bk,
@@ -274,7 +292,7 @@ extern "C" int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t n
     return sagnn::fail(SAGNN_ERR_WORKSPACE, "fusion workspace needs %zu bytes", need);
   float* h = static_cast<float*>(workspace);
   const int64_t ldw = (int64_t)t * d;
-  if (int rc = sagnn_lstm_fwd_f32(x, ld_n, n, t, d, lstm_W, lstm_b, forget_bias, nullptr, h, ldw, stream)) return rc;
-  if (int rc = sagnn_layernorm_td_f32(h, ldw, n, t, d, ln_gamma, ln_beta, ln_eps, h, ldw, stream)) return rc;
-  return sagnn_mhsa_mean_f32(h, ldw, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out, stream);
+  if (int rc = sagnn_lstm_fwd_f32(x, ld_n, ld_t, n, t, d, lstm_W, lstm_b, forget_bias, nullptr, h, ldw, stream)) return rc;
+  if (int rc = sagnn_layernorm_td_f32(h, ldw, d, n, t, d, ln_gamma, ln_beta, ln_eps, h, ldw, stream)) return rc;
+  return sagnn_mhsa_mean_f32(h, ldw, d, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out, stream);
 }

@@ -421,6 +421,7 @@ int launch_spmm(const sagnn_spmm_plan* p, const float* X, int64_t ldx, int d, co
   const int64_t blocks = chunk_blocks + row_blocks;
   if (blocks > INT32_MAX) return sagnn::fail(SAGNN_ERR_ARG, "grid too large");
   if (blocks > 0) {
+    sagnn::ProfileScope prof(sagnn::kProfSpmmRows, stream, p->info.nnz, n_rows);
     hipLaunchKernelGGL(spmm_rows_kernel<LPR>, dim3((unsigned)blocks), dim3(kBlock), 0, stream,
                        p->d_rowptr, p->d_colidx, X, ldx, d, n_rows, p->info.short_thresh,
                        p->info.long_thresh, p->d_chunk_e0, p->d_chunk_e1, n_chunks,
@@ -429,6 +430,7 @@ int launch_spmm(const sagnn_spmm_plan* p, const float* X, int64_t ldx, int d, co
   }
   const int64_t n_long = p->info.n_long_rows;
   if (n_long > 0) {
+    sagnn::ProfileScope prof(sagnn::kProfSpmmFixup, stream, n_chunks, n_long);
     const int64_t fb = (n_long + kWavesPerBlock - 1) / kWavesPerBlock;
     hipLaunchKernelGGL(spmm_fixup_kernel<LPR>, dim3((unsigned)fb), dim3(kBlock), 0, stream,
                        p->d_long_row, p->d_long_slot, n_long, partial, d, ep);

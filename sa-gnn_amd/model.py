@@ -20,6 +20,25 @@ from .Utils.attention import MultiHeadSelfAttention
 from .graph import interval_pair
 
 
+def random_fusion_params(d: int, device, seed: int = 0) -> dict:
+    """Random-init fusion parameters with the shapes TF creates (BasicLSTMCell kernel [2d, 4d] and
+    bias [4d]; layer_norm gamma/beta [d]; three dense kernels [d, d] with bias [d]). Kernels are
+    xavier-uniform; biases/beta get small random values so benchmarks and tests exercise them."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+
+    def xavier(r, c):
+        lim = (6.0 / (r + c)) ** 0.5
+        return (torch.rand((r, c), generator=g) * 2 * lim - lim).to(device)
+
+    def small(n, mean=0.0):
+        return (mean + 0.1 * torch.randn(n, generator=g)).to(device)
+
+    return {"lstm_W": xavier(2 * d, 4 * d), "lstm_b": small(4 * d), "ln_gamma": small(d, 1.0),
+            "ln_beta": small(d), "Wq": xavier(d, d), "bq": small(d), "Wk": xavier(d, d), "bk": small(d),
+            "Wv": xavier(d, d), "bv": small(d)}
+
+
 class Recommender:
     def __init__(self, sess, handler):
         self.sess = sess

@@ -166,13 +166,19 @@ def gnn_interval(plan_user: SpmmPlan, plan_item: SpmmPlan, u0: torch.Tensor, i0:
     return user_out, item_out
 
 
-def _ntd(name: str, x: torch.Tensor):
+def _ntd(name: str, x: torch.Tensor, dense_td: bool = False):
+    """x is indexed [node, interval, feature]; any node/interval strides (so a permuted view of
+    [t, n, d] storage works). Returns n, t, d, ld_n, ld_t."""
     if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 3:
-        raise TypeError(f"{name}: expected a float32 device tensor [n, t, d]")
-    n, t, d = x.shape
-    if x.stride(2) != 1 or x.stride(1) != d:
+        raise TypeError(f"{name}: expected a float32 device tensor indexed [n, t, d]")
+    n, t, d = (int(v) for v in x.shape)
+    if x.stride(2) != 1:
+        raise ValueError(f"{name}: the feature axis must have unit stride")
+    ld_n = int(x.stride(0)) if n > 1 else max(int(x.stride(0)), d)
+    ld_t = int(x.stride(1)) if t > 1 else max(int(x.stride(1)), d)
+    if dense_td and ld_t != d:
         raise ValueError(f"{name}: the (t, d) block of each node must be contiguous")
-    return int(n), int(t), int(d), (int(x.stride(0)) if n > 1 else t * d)
+    return n, t, d, ld_n, ld_t
 
 
 def _vec(name: str, v: torch.Tensor, numel: int):
@@ -184,13 +190,13 @@ def _vec(name: str, v: torch.Tensor, numel: int):
 def lstm_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, forget_bias: float = 1.0,
              drop_scale: torch.Tensor | None = None, out: torch.Tensor | None = None):
     """BasicLSTMCell over T (reference model.py:135-146): sagnn_lstm_fwd_f32. x [n, t, d]."""
-    n, t, d, ld = _ntd("x", x)
+    n, t, d, ld, ldt = _ntd("x", x)
     if out is None:
         out = torch.empty((n, t, d), dtype=torch.float32, device=x.device)
-    _, _, _, ldh = _ntd("out", out)
+    _, _, _, ldh, _ = _ntd("out", out, dense_td=True)
     if drop_scale is not None and (not drop_scale.is_contiguous() or drop_scale.shape != x.shape):
         raise ValueError("drop_scale must be contiguous [n, t, d]")
-    check(_lib.load().sagnn_lstm_fwd_f32(x.data_ptr(), ld, n, t, d, _vec("W", W, 8 * d * d),
+    check(_lib.load().sagnn_lstm_fwd_f32(x.data_ptr(), ld, ldt, n, t, d, _vec("W", W, 8 * d * d),
                                          _vec("b", b, 4 * d), float(forget_bias), _ptr(drop_scale),
                                          out.data_ptr(), ldh, _stream()))
     return out
@@ -199,11 +205,11 @@ def lstm_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, forget_bias: flo
 def layernorm_td(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-12,
                  out: torch.Tensor | None = None):
     """layer_norm over (t, d) per node (reference model.py:152-153): sagnn_layernorm_td_f32."""
-    n, t, d, ld = _ntd("x", x)
+    n, t, d, ld, ldt = _ntd("x", x)
     if out is None:
         out = torch.empty((n, t, d), dtype=torch.float32, device=x.device)
-    _, _, _, ldy = _ntd("out", out)
-    check(_lib.load().sagnn_layernorm_td_f32(x.data_ptr(), ld, n, t, d, _vec("gamma", gamma, d),
+    _, _, _, ldy, _ = _ntd("out", out, dense_td=True)
+    check(_lib.load().sagnn_layernorm_td_f32(x.data_ptr(), ld, ldt, n, t, d, _vec("gamma", gamma, d),
                                              _vec("beta", beta, d), float(eps), out.data_ptr(), ldy,
                                              _stream()))
     return out
@@ -212,12 +218,12 @@ def layernorm_td(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: 
 def mhsa_mean(x: torch.Tensor, Wq, bq, Wk, bk, Wv, bv, heads: int, out: torch.Tensor | None = None):
     """MultiHeadSelfAttention + mean over T (reference Utils/attention.py:55-78, model.py:154-155):
     sagnn_mhsa_mean_f32. x [n, t, d] -> [n, d]."""
-    n, t, d, ld = _ntd("x", x)
+    n, t, d, ld, ldt = _ntd("x", x)
     if out is None:
         out = torch.empty((n, d), dtype=torch.float32, device=x.device)
     ldo = _f32_rows("out", out, d, n)
     check(_lib.load().sagnn_mhsa_mean_f32(
-        x.data_ptr(), ld, n, t, d, int(heads), _vec("Wq", Wq, d * d), _vec("bq", bq, d),
+        x.data_ptr(), ld, ldt, n, t, d, int(heads), _vec("Wq", Wq, d * d), _vec("bq", bq, d),
         _vec("Wk", Wk, d * d), _vec("bk", bk, d), _vec("Wv", Wv, d * d), _vec("bv", bv, d),
         out.data_ptr(), ldo, _stream()))
     return out
@@ -228,7 +234,7 @@ def interval_fusion(x: torch.Tensor, p: dict, heads: int, out: torch.Tensor | No
     """LSTM -> layer_norm -> MHSA -> mean (reference model.py:135-155): sagnn_interval_fusion_f32.
     p: lstm_W [2d,4d], lstm_b [4d], ln_gamma [d], ln_beta [d], Wq/bq/Wk/bk/Wv/bv."""
     lib = _lib.load()
-    n, t, d, ld = _ntd("x", x)
+    n, t, d, ld, ldt = _ntd("x", x)
     if out is None:
         out = torch.empty((n, d), dtype=torch.float32, device=x.device)
     ldo = _f32_rows("out", out, d, n)
@@ -236,7 +242,7 @@ def interval_fusion(x: torch.Tensor, p: dict, heads: int, out: torch.Tensor | No
     if workspace is None or workspace.numel() * workspace.element_size() < need:
         workspace = torch.empty(max(need // 4, 1), dtype=torch.float32, device=x.device)
     check(lib.sagnn_interval_fusion_f32(
-        x.data_ptr(), ld, n, t, d, int(heads), _vec("lstm_W", p["lstm_W"], 8 * d * d),
+        x.data_ptr(), ld, ldt, n, t, d, int(heads), _vec("lstm_W", p["lstm_W"], 8 * d * d),
         _vec("lstm_b", p["lstm_b"], 4 * d), 1.0, _vec("ln_gamma", p["ln_gamma"], d),
         _vec("ln_beta", p["ln_beta"], d), 1e-12, _vec("Wq", p["Wq"], d * d), _vec("bq", p["bq"], d),
         _vec("Wk", p["Wk"], d * d), _vec("bk", p["bk"], d), _vec("Wv", p["Wv"], d * d),

@@ -1,0 +1,113 @@
+"""Interval-parallel execution of the hot path: one process per GPU, torch.distributed (backend
+"nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for the tests).
+
+The reference is single-process; its loop body model.py:118-129 has no dependency
+across intervals, the first cross-interval op is the stack at model.py:131-132. So:
+
+  1. interval k runs on rank k mod world (its CSR pair and embedding slabs live only there);
+  2. exchange: every rank sends the row shard r of each of its interval outputs to rank r
+     (all-to-all). Rank r ends up with x_r [T, rows_r, d] — all intervals, its rows — received
+     straight into place, no staging copy; this moves 1/world of what an all-gather of the
+     stacked [T_local, N, d] tensors would (SURVEY.md §8e caveat 1);
+  3. fusion (LSTM -> LN -> MHSA -> mean) is row-independent: rank r fuses its rows;
+  4. RCCL all-gather reassembles the fused embeddings [N, d] on every rank.
+
+`exchange="allgather"` keeps the plain form of step 2 (all-gather of the stacked interval
+outputs, then each rank slices its rows) for comparison.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class IntervalSharding:
+    """Static maps: interval -> rank (cyclic) and node row -> rank (contiguous, balanced)."""
+
+    def __init__(self, n_intervals: int, world: int, rank: int):
+        if not (0 <= rank < world):
+            raise ValueError(f"rank {rank} outside world {world}")
+        self.T, self.world, self.rank = int(n_intervals), int(world), int(rank)
+        self.rounds = -(-self.T // self.world)            # all-to-all calls every rank takes part in
+
+    def owner(self, k: int) -> int:
+        return k % self.world
+
+    def intervals_of(self, r: int):
+        return list(range(r, self.T, self.world))
+
+    @property
+    def local_intervals(self):
+        return self.intervals_of(self.rank)
+
+    def row_bounds(self, n_rows: int):
+        """world+1 offsets; shard r = [b[r], b[r+1]), sizes differ by at most one."""
+        q, rem = divmod(int(n_rows), self.world)
+        b = [0]
+        for r in range(self.world):
+            b.append(b[-1] + q + (1 if r < rem else 0))
+        return b
+
+    def row_range(self, n_rows: int, r: int | None = None):
+        b = self.row_bounds(n_rows)
+        r = self.rank if r is None else r
+        return b[r], b[r + 1]
+
+
+def exchange_to_row_shards(local_out: torch.Tensor, sh: IntervalSharding, n_rows: int, group=None,
+                           mode: str = "alltoall") -> torch.Tensor:
+    """local_out [T_local, N, d]: this rank's interval outputs in local order (interval
+    rank + j*world at index j). Returns x [T, rows_local, d] in global interval order."""
+    d = local_out.shape[-1]
+    if sh.world == 1:
+        return local_out                                   # already [T, N, d]; nothing to move
+    lo, hi = sh.row_range(n_rows)
+    x = torch.empty((sh.T, hi - lo, d), dtype=local_out.dtype, device=local_out.device)
+    bounds = sh.row_bounds(n_rows)
+    if mode == "alltoall":
+        # all_to_all_single per round j: the input is this rank's j-th interval output split by
+        # destination row shard; the blocks arrive in sender order s = 0..world-1, i.e. as the
+        # global intervals j*world + s, which are adjacent slabs of x — received in place.
+        in_splits = [bounds[r + 1] - bounds[r] for r in range(sh.world)]
+        for j in range(sh.rounds):
+            have = j < local_out.shape[0]
+            cnt = min(sh.world, sh.T - j * sh.world)       # senders that own a j-th interval
+            out_splits = [(hi - lo) if s < cnt else 0 for s in range(sh.world)]
+            recv = x[j * sh.world: j * sh.world + cnt].view(cnt * (hi - lo), d)
+            send = local_out[j] if have else local_out.new_empty((0, d))
+            dist.all_to_all_single(recv, send, output_split_sizes=out_splits,
+                                   input_split_sizes=in_splits if have else [0] * sh.world,
+                                   group=group)
+        return x
+    if mode == "allgather":
+        t_loc = sh.rounds
+        pad = local_out
+        if local_out.shape[0] < t_loc:                    # ranks with one interval fewer pad a slab
+            pad = torch.zeros((t_loc, n_rows, d), dtype=local_out.dtype, device=local_out.device)
+            pad[:local_out.shape[0]] = local_out
+        full = torch.empty((sh.world * t_loc, n_rows, d), dtype=local_out.dtype, device=local_out.device)
+        dist.all_gather_into_tensor(full, pad.contiguous(), group=group)
+        for k in range(sh.T):
+            x[k].copy_(full[(k % sh.world) * t_loc + k // sh.world, lo:hi])
+        return x
+    raise ValueError(f"unknown exchange mode {mode!r}")
+
+
+def gather_fused(final_local: torch.Tensor, sh: IntervalSharding, n_rows: int, group=None) -> torch.Tensor:
+    """All-gather of the fused embeddings: [rows_local, d] on each rank -> [N, d] everywhere."""
+    d = final_local.shape[-1]
+    if sh.world == 1:
+        return final_local
+    out = torch.empty((n_rows, d), dtype=final_local.dtype, device=final_local.device)
+    bounds = sh.row_bounds(n_rows)
+    if n_rows % sh.world == 0:
+        dist.all_gather_into_tensor(out, final_local.contiguous(), group=group)
+    else:                                                  # pad every shard to the largest one
+        rmax = bounds[1] - bounds[0]
+        mine = final_local.new_zeros((rmax, d))
+        mine[: final_local.shape[0]] = final_local
+        full = final_local.new_empty((sh.world * rmax, d))
+        dist.all_gather_into_tensor(full, mine, group=group)
+        for r in range(sh.world):
+            out[bounds[r]:bounds[r + 1]] = full[r * rmax: r * rmax + bounds[r + 1] - bounds[r]]
+    return out

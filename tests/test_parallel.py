@@ -1,0 +1,86 @@
+"""CPU suite, part 3: the interval-sharded exchange (world_size 2 and 3, gloo). Every rank computes
+its intervals with the ORACLE (this is a test of the sharding maps and the collectives, not of
+the kernels), exchanges, fuses its row shard with the oracle, all-gathers — and must reproduce the
+single-process oracle result exactly."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import selfgnn_oracle as O
+from sa_gnn_amd.parallel import IntervalSharding, exchange_to_row_shards, gather_fused
+
+
+def _problem(T, U, I, d, seed=3):
+    rng = np.random.default_rng(seed)
+    mats = [sp.csr_matrix((rng.random((U, I)) < 0.1).astype(np.intc)) for _ in range(T)]
+    ue = rng.standard_normal((T, U, d)).astype(np.float32)
+    ie = rng.standard_normal((T, I, d)).astype(np.float32)
+    return mats, ue, ie, O.init_fusion_params(d, rng)
+
+
+def _worker(rank, world, port, T, mode, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        U, I, d = 23, 17, 16
+        mats, ue, ie, p = _problem(T, U, I, d)
+        sh = IntervalSharding(T, world, rank)
+        outs_u = []
+        for k in sh.local_intervals:                     # only this rank's intervals are computed
+            u, _ = O.gnn_interval(ue[k], ie[k], O.trans_to_lsts(mats[k])[0],
+                                  O.trans_to_lsts(O.transpose(mats[k]))[0], 2, 0.5)
+            outs_u.append(u)
+        local = torch.from_numpy(np.stack(outs_u, 0)) if outs_u else torch.empty((0, U, d))
+        x = exchange_to_row_shards(local, sh, U, mode=mode)          # [T, rows_local, d]
+        lo, hi = sh.row_range(U)
+        assert x.shape == (T, hi - lo, d)
+        fused = O.interval_fusion(x.permute(1, 0, 2).numpy(), p, 4)
+        full = gather_fused(torch.from_numpy(fused), sh, U)
+        q.put((rank, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,T,mode", [(2, 4, "alltoall"), (2, 3, "alltoall"), (3, 4, "alltoall"),
+                                          (2, 1, "alltoall"), (2, 3, "allgather")])
+def test_interval_sharded_pipeline_matches_single_process(world, T, mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, T, mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mats, ue, ie, p = _problem(T, 23, 17, 16)
+    uv, _ = O.gnn_stack(ue, ie, [O.trans_to_lsts(m)[0] for m in mats],
+                        [O.trans_to_lsts(O.transpose(m))[0] for m in mats], 2, 0.5)
+    want = O.interval_fusion(uv, p, 4)
+    for r in range(world):
+        np.testing.assert_allclose(results[r], want, rtol=1e-6, atol=1e-6)
+
+
+def test_sharding_maps():
+    sh = IntervalSharding(16, 8, 3)
+    assert sh.local_intervals == [3, 11] and sh.rounds == 2 and sh.owner(11) == 3
+    assert IntervalSharding(5, 8, 6).local_intervals == [] and IntervalSharding(5, 8, 4).local_intervals == [4]
+    b = IntervalSharding(3, 4, 0).row_bounds(10)
+    assert b == [0, 3, 6, 8, 10]
+    assert sorted(k for r in range(8) for k in IntervalSharding(13, 8, r).local_intervals) == list(range(13))
+    with pytest.raises(ValueError):
+        IntervalSharding(4, 2, 2)
