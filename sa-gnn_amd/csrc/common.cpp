@@ -2,6 +2,7 @@
 #include "common.h"
 
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -29,6 +30,11 @@ int hip_fail(hipError_t e, const char* what) {
   snprintf(buf, sizeof buf, "%s: %s (hipError %d)", what, hipGetErrorString(e), (int)e);
   last_error_slot() = buf;
   return (int)e;
+}
+
+bool force_valu() {
+  const char* v = getenv("SAGNN_FUSION");
+  return v && strcmp(v, "valu") == 0;
 }
 
 // ---- profiler ---------------------------------------------------------------------------------

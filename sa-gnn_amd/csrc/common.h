@@ -30,6 +30,13 @@ inline int lanes_per_row(int d) {
   return lpr;  // 8, 16, 32 or 64 for d <= 256
 }
 
+// fusion_mfma.hip
+bool lstm_mfma_supported(int d);
+int lstm_fwd_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
+                  const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
+                  hipStream_t s);
+bool force_valu();  // SAGNN_FUSION=valu in the environment
+
 // ---- optional per-launch timing (sagnn_profile_*) -------------------------------------------
 enum ProfileKind { kProfSpmmRows = 0, kProfSpmmFixup = 1, kProfLstm = 2, kProfLayerNorm = 3, kProfMhsa = 4 };
 

@@ -237,6 +237,12 @@ extern "C" int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t ld_t, in
   if (int rc = check_strides(ld_n, ld_t, n, t, d)) return rc;
   if (ld_h < (int64_t)t * d) return sagnn::fail(SAGNN_ERR_ARG, "ld_h smaller than t*d");
   if (n == 0) return SAGNN_OK;
+  // matrix-core path: d = 32 / 64 with 16-byte aligned rows; SAGNN_FUSION=valu forces the
+  // VALU formulation (A/B runs)
+  const bool vec_ok = sagnn::aligned16(x) && (ld_n & 3) == 0 && (ld_t & 3) == 0;
+  if (sagnn::lstm_mfma_supported(d) && vec_ok && !sagnn::force_valu())
+    return sagnn::lstm_fwd_mfma(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h,
+                                static_cast<hipStream_t>(stream));
   return sagnn::lstm_fwd_valu(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h,
                               static_cast<hipStream_t>(stream));
 }
