@@ -35,6 +35,11 @@ bool lstm_mfma_supported(int d);
 int lstm_fwd_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
                   const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
                   hipStream_t s);
+bool mhsa_mfma_supported(int d, int t, int heads);
+int ln_mhsa_mean_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
+                      const float* gamma, const float* beta, float eps, int apply_ln, const float* Wq,
+                      const float* bq, const float* Wk, const float* bk, const float* Wv,
+                      const float* bv, float* out, int64_t ld_out, hipStream_t s);
 bool force_valu();  // SAGNN_FUSION=valu in the environment
 
 // ---- optional per-launch timing (sagnn_profile_*) -------------------------------------------

@@ -275,6 +275,10 @@ extern "C" int sagnn_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t ld_t, i
   if (int rc = check_strides(ld_n, ld_t, n, t, d)) return rc;
   if (ld_out < d) return sagnn::fail(SAGNN_ERR_ARG, "ld_out smaller than d");
   if (n == 0) return SAGNN_OK;
+  const bool vec_ok = sagnn::aligned16(x) && (ld_n & 3) == 0 && (ld_t & 3) == 0;
+  if (sagnn::mhsa_mfma_supported(d, t, heads) && vec_ok && !sagnn::force_valu())
+    return sagnn::ln_mhsa_mean_mfma(x, ld_n, ld_t, n, t, d, heads, nullptr, nullptr, 0.f, 0, Wq, bq, Wk,
+                                    bk, Wv, bv, out, ld_out, static_cast<hipStream_t>(stream));
   return sagnn::mhsa_mean_valu(x, ld_n, ld_t, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out,
                                static_cast<hipStream_t>(stream));
 }
@@ -298,7 +302,16 @@ extern "C" int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t l
     return sagnn::fail(SAGNN_ERR_WORKSPACE, "fusion workspace needs %zu bytes", need);
   float* h = static_cast<float*>(workspace);
   const int64_t ldw = (int64_t)t * d;
+  if (heads < 1 || d % heads) return sagnn::fail(SAGNN_ERR_DIM, "heads = %d does not divide d = %d", heads, d);
+  if (!ln_gamma || !ln_beta || !Wq || !bq || !Wk || !bk || !Wv || !bv || !out)
+    return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
   if (int rc = sagnn_lstm_fwd_f32(x, ld_n, ld_t, n, t, d, lstm_W, lstm_b, forget_bias, nullptr, h, ldw, stream)) return rc;
+  if (n == 0) return SAGNN_OK;
+  // layer norm rides on the attention kernel's A operand when the matrix-core path applies:
+  // h is read once and never rewritten
+  if (sagnn::mhsa_mfma_supported(d, t, heads) && !sagnn::force_valu())
+    return sagnn::ln_mhsa_mean_mfma(h, ldw, d, n, t, d, heads, ln_gamma, ln_beta, ln_eps, 1, Wq, bq, Wk, bk,
+                                    Wv, bv, out, ld_out, static_cast<hipStream_t>(stream));
   if (int rc = sagnn_layernorm_td_f32(h, ldw, d, n, t, d, ln_gamma, ln_beta, ln_eps, h, ldw, stream)) return rc;
   return sagnn_mhsa_mean_f32(h, ldw, d, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out, stream);
 }

@@ -207,6 +207,261 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// layer_norm over (T, d) -> Q/K/V dense -> exp attention -> mean over queries
+// (reference model.py:152-155, Utils/attention.py:35-45, 55-78), one pass over h.
+//
+// A wavefront owns NB = 32 / T nodes = NB*T GEMM rows (row m = nb*T + t). The normalisation is
+// applied to the A operand in registers (each lane holds half of one row), the three [d, d]
+// products run as MFMAs against fragment-ordered weights in LDS, Q/K/V go to a per-wave LDS
+// tile, and the T x T attention of each head is evaluated with lane = feature column
+// (scores are reduced across the d_k adjacent lanes of a head).
+// ---------------------------------------------------------------------------------------------
+// Sum over the dk adjacent lanes of a head (dk a power of two). dk <= 4 stays on DPP quad
+// permutes; wider heads fall back to ds_bpermute shuffles.
+__device__ __forceinline__ float head_sum(float p, int dk) {
+  if (dk >= 2) p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xF, 0xF, true));
+  if (dk >= 4) p += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x4E, 0xF, 0xF, true));
+  for (int off = 4; off < dk; off <<= 1) p += __shfl_xor(p, off);
+  return p;
+}
+
+template <int TM>
+__device__ __forceinline__ void load_square_fragments(float* __restrict__ Wf,
+                                                      const float* __restrict__ W, int D) {
+  // Wf[(kk*64 + l)*TM + e] = W[2kk + (l>>5)][e*32 + (l&31)],  kk < D/2
+  const int total = D * D;
+  for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+    const int e = idx % TM;
+    const int l = (idx / TM) & 63;
+    const int kk = idx / (TM * 64);
+    Wf[idx] = W[(size_t)(2 * kk + (l >> 5)) * D + e * 32 + (l & 31)];
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
+    const float* __restrict__ x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int heads,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int apply_ln,
+    const float* __restrict__ Wq, const float* __restrict__ bq, const float* __restrict__ Wk,
+    const float* __restrict__ bk, const float* __restrict__ Wv, const float* __restrict__ bv,
+    float* __restrict__ out, int64_t ld_out, int64_t n_tiles) {
+  constexpr int TM = D / 32;       // 32-column tiles per weight matrix
+  constexpr int KS = D / 2;        // k-steps
+  constexpr int LPR = D / 4;
+  constexpr int RPI = kWave / LPR;
+  constexpr int NFILL = kRowsPerWave / RPI;
+  constexpr int QS = 3 * D;        // row stride of the per-wave Q|K|V tile
+  constexpr int NPP = kWave / D;   // nodes per attention pass (1 at D=64, 2 at D=32)
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Wqf = lds;
+  float* Wkf = lds + D * D;
+  float* Wvf = lds + 2 * D * D;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* qkv = lds + 3 * D * D + wave * (kRowsPerWave * QS);  // private [32][3D]; its head
+  float* stage = qkv;                                         // doubles as the [32][D] fill tile
+  const int ai = lane & 31, kh = lane >> 5;
+  const int cj = lane & 31, rh = lane >> 5;
+  const int fr = lane / LPR, fc4 = (lane % LPR) * 4;
+
+  load_square_fragments<TM>(Wqf, Wq, D);
+  load_square_fragments<TM>(Wkf, Wk, D);
+  load_square_fragments<TM>(Wvf, Wv, D);
+  __syncthreads();
+
+  const int nb_per_wave = kRowsPerWave / t;      // nodes per wave tile (t <= 32)
+  const int rows_used = nb_per_wave * t;
+  const int dk = D / heads;
+  const float scale = 1.f / sqrtf((float)dk);
+  const float inv_td = 1.f / (float)(t * D);
+  const float inv_t = 1.f / (float)t;
+
+  float gam[KS], bet[KS];
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    gam[kk] = apply_ln ? gamma[2 * kk + kh] : 1.f;
+    bet[kk] = apply_ln ? beta[2 * kk + kh] : 0.f;
+  }
+  float bqc[TM], bkc[TM], bvc[TM];
+#pragma unroll
+  for (int e = 0; e < TM; ++e) {
+    bqc[e] = bq[e * 32 + cj];
+    bkc[e] = bk[e * 32 + cj];
+    bvc[e] = bv[e * 32 + cj];
+  }
+
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t node0 = (tile * 4 + wave) * nb_per_wave;
+    if (node0 >= n) continue;  // wave-uniform
+    int ai_ = ai, kh_ = kh, cj_ = cj, rh_ = rh, fr_ = fr, fc4_ = fc4;
+    asm volatile("" : "+v"(ai_), "+v"(kh_), "+v"(cj_), "+v"(rh_), "+v"(fr_), "+v"(fc4_));
+
+    // ---- fill the [32][D] tile: row m = nb*t + ts ------------------------------------------
+#pragma unroll
+    for (int q = 0; q < NFILL; ++q) {
+      const int m = q * RPI + fr_;
+      const int nb = m / t, ts = m - nb * t;
+      const int64_t node = node0 + nb;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < rows_used && node < n)
+        v = *reinterpret_cast<const float4*>(x + node * ld_n + (int64_t)ts * ld_t + fc4_);
+      const int sw = m & 31;
+      float* dst = stage + m * D;
+      dst[(fc4_ + 0) ^ sw] = v.x;
+      dst[(fc4_ + 1) ^ sw] = v.y;
+      dst[(fc4_ + 2) ^ sw] = v.z;
+      dst[(fc4_ + 3) ^ sw] = v.w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float a[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) a[kk] = stage[ai_ * D + ((2 * kk + kh_) ^ ai_)];
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- layer norm on the A operand: moments over the node's t rows x D columns ----------
+    if (apply_ln) {
+      const int base = (ai_ / t) * t;               // first row of this lane's node
+      float ps = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) ps += a[kk];
+      ps += __shfl_xor(ps, 32);
+      float tot = 0.f;
+      for (int ts = 0; ts < t; ++ts) tot += __shfl(ps, (base + ts) & 31);
+      const float mean = tot * inv_td;
+      float pv = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const float dl = a[kk] - mean;
+        pv = fmaf(dl, dl, pv);
+      }
+      pv += __shfl_xor(pv, 32);
+      float var = 0.f;
+      for (int ts = 0; ts < t; ++ts) var += __shfl(pv, (base + ts) & 31);
+      const float rstd = rsqrtf(var * inv_td + eps);
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const float inv = rstd * gam[kk];
+        a[kk] = a[kk] * inv + (bet[kk] - mean * inv);
+      }
+    }
+
+    // ---- Q | K | V = A @ W + b ---------------------------------------------------------------
+    f32x16 aq[TM], ak[TM], av[TM];
+#pragma unroll
+    for (int e = 0; e < TM; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        aq[e][r] = 0.f;
+        ak[e][r] = 0.f;
+        av[e][r] = 0.f;
+      }
+    {
+      float wq[TM], wk[TM], wv[TM], nq[TM], nk[TM], nv[TM];
+#pragma unroll
+      for (int e = 0; e < TM; ++e) {
+        wq[e] = Wqf[lane * TM + e];
+        wk[e] = Wkf[lane * TM + e];
+        wv[e] = Wvf[lane * TM + e];
+      }
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        if (kk + 1 < KS) {
+#pragma unroll
+          for (int e = 0; e < TM; ++e) {
+            nq[e] = Wqf[((kk + 1) * 64 + lane) * TM + e];
+            nk[e] = Wkf[((kk + 1) * 64 + lane) * TM + e];
+            nv[e] = Wvf[((kk + 1) * 64 + lane) * TM + e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < TM; ++e) {
+          aq[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], wq[e], aq[e], 0, 0, 0);
+          ak[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], wk[e], ak[e], 0, 0, 0);
+          av[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], wv[e], av[e], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < TM; ++e) {
+          wq[e] = nq[e];
+          wk[e] = nk[e];
+          wv[e] = nv[e];
+        }
+      }
+    }
+
+    // ---- Q | K | V tile to LDS (C layout -> row major) --------------------------------------
+#pragma unroll
+    for (int e = 0; e < TM; ++e)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float* dst = qkv + crow(r, rh_) * QS + e * 32 + cj_;
+        dst[0] = aq[e][r] + bqc[e];
+        dst[D] = ak[e][r] + bkc[e];
+        dst[2 * D] = av[e][r] + bvc[e];
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- attention per node and head, lane = feature column --------------------------------
+    // NPAR independent nodes are interleaved so their LDS reads, head reductions and exps
+    // overlap (one node's (tq, s) chain alone is latency-bound).
+    const int col = lane % D;
+    const int sub = lane / D;                       // node parity inside a pass (D = 32)
+    constexpr int NPAR = 4;
+    for (int nb0 = 0; nb0 < nb_per_wave; nb0 += NPP * NPAR) {
+      const float* base[NPAR];
+      float o[NPAR];
+      bool live[NPAR];
+#pragma unroll
+      for (int u = 0; u < NPAR; ++u) {
+        const int nb = nb0 + u * NPP + sub;
+        live[u] = nb < nb_per_wave;
+        base[u] = qkv + (live[u] ? nb : 0) * t * QS + col;
+        o[u] = 0.f;
+      }
+      for (int tq = 0; tq < t; ++tq) {
+        float qv[NPAR], rs[NPAR], ctx[NPAR];
+#pragma unroll
+        for (int u = 0; u < NPAR; ++u) {
+          qv[u] = base[u][tq * QS];
+          rs[u] = 0.f;
+          ctx[u] = 0.f;
+        }
+        for (int s = 0; s < t; ++s) {
+          float p[NPAR], vv[NPAR];
+#pragma unroll
+          for (int u = 0; u < NPAR; ++u) {
+            p[u] = qv[u] * base[u][s * QS + D];
+            vv[u] = base[u][s * QS + 2 * D];
+          }
+#pragma unroll
+          for (int u = 0; u < NPAR; ++u) p[u] = head_sum(p[u], dk);
+#pragma unroll
+          for (int u = 0; u < NPAR; ++u) {
+            const float e = __expf(p[u] * scale);
+            rs[u] += e;
+            ctx[u] = fmaf(e, vv[u], ctx[u]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NPAR; ++u) o[u] = fmaf(ctx[u], __builtin_amdgcn_rcpf(rs[u] + 1e-8f), o[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < NPAR; ++u) {
+        const int64_t node = node0 + nb0 + u * NPP + sub;
+        if (live[u] && node < n) out[node * ld_out + col] = o[u] * inv_t;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace
 
 namespace sagnn {
@@ -244,6 +499,52 @@ int lstm_fwd_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, 
   if (d == 64) return launch_lstm_mfma<64>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, s);
   if (d == 32) return launch_lstm_mfma<32>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, s);
   return fail(SAGNN_ERR_DIM, "MFMA LSTM supports d = 32 or 64, got %d", d);
+}
+
+bool mhsa_mfma_supported(int d, int t, int heads) {
+  if (!(d == 32 || d == 64) || t < 1 || t > 32 || heads < 1 || d % heads) return false;
+  const int dk = d / heads;
+  return (dk & (dk - 1)) == 0;  // the per-head lane reduction needs a power of two
+}
+
+template <int D>
+static int launch_ln_mhsa(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int heads,
+                          const float* gamma, const float* beta, float eps, int apply_ln,
+                          const float* Wq, const float* bq, const float* Wk, const float* bk,
+                          const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s) {
+  const size_t lds = (size_t)(3 * D * D + 4 * kRowsPerWave * 3 * D) * sizeof(float);
+  static bool configured = false;
+  if (!configured) {
+    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_mhsa_mean_mfma_kernel<D>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const int64_t nodes_per_tile = 4 * (kRowsPerWave / t);
+  const int64_t n_tiles = (n + nodes_per_tile - 1) / nodes_per_tile;
+  const int64_t blocks = n_tiles < cus ? n_tiles : cus;
+  ProfileScope prof(kProfMhsa, s, n, t);
+  hipLaunchKernelGGL(ln_mhsa_mean_mfma_kernel<D>, dim3((unsigned)blocks), dim3(kBlock), lds, s, x, ld_n,
+                     ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out,
+                     n_tiles);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+// apply_ln = 0: plain MHSA + mean (gamma/beta ignored); 1: layer_norm over (t, d) first.
+int ln_mhsa_mean_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
+                      const float* gamma, const float* beta, float eps, int apply_ln, const float* Wq,
+                      const float* bq, const float* Wk, const float* bk, const float* Wv,
+                      const float* bv, float* out, int64_t ld_out, hipStream_t s) {
+  if (d == 64)
+    return launch_ln_mhsa<64>(x, ld_n, ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
+  if (d == 32)
+    return launch_ln_mhsa<32>(x, ld_n, ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
+  return fail(SAGNN_ERR_DIM, "MFMA attention supports d = 32 or 64, got %d", d);
 }
 
 }  // namespace sagnn
