@@ -74,7 +74,7 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     import torch.distributed as dist
     from sa_gnn_amd import _lib, ops, synthetic
-    from sa_gnn_amd.parallel import IntervalSharding, exchange_to_row_shards, gather_fused
+    from sa_gnn_amd.parallel import IntervalSharding, RowShardExchange, exchange_to_row_shards, gather_fused
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -122,21 +122,31 @@ def main():
     fuse_ws = torch.empty(1, device=dev)
     state = {}
 
+    # N > 1: row-shard exchange buffers; round j is posted right after interval j's SpMM stack and
+    # travels over xGMI under the next interval's SpMMs (--exchange allgather: one blocking
+    # all-gather of the stacked outputs instead, for comparison)
+    overlap = world > 1 and a.exchange == "alltoall"
+    ex_u = RowShardExchange(sh, U, d, dev) if overlap else None
+    ex_i = RowShardExchange(sh, I, d, dev) if overlap else None
+
     def step():
+        nonlocal fuse_ws
         for j in range(t_loc):
             ops.gnn_interval(plans[j][0], plans[j][1], emb[j][0], emb[j][1], L, 0.5, out_u[j], out_i[j], scr_u, scr_i)
+            if overlap and a.stages == "full":
+                ex_u.post(out_u[j])
+                ex_i.post(out_i[j])
         if a.stages == "spmm":
             return
-        nonlocal fuse_ws
-        finals = []
-        for x_loc, n_rows, p in ((out_u, U, prm[0]), (out_i, I, prm[1])):
-            x = exchange_to_row_shards(x_loc, sh, n_rows, mode=a.exchange)          # [T, rows_local, d]
-            need = x.shape[0] * x.shape[1] * d
+        pending = []
+        for x_loc, n_rows, p, ex in ((out_u, U, prm[0], ex_u), (out_i, I, prm[1], ex_i)):
+            x = ex.finish() if overlap else exchange_to_row_shards(x_loc, sh, n_rows, mode=a.exchange)
+            need = x.shape[0] * x.shape[1] * d                                   # [T, rows_local, d]
             if fuse_ws.numel() < need:
                 fuse_ws = torch.empty(need, device=dev)
             f = ops.interval_fusion(x.permute(1, 0, 2), p, heads, workspace=fuse_ws)
-            finals.append(gather_fused(f, sh, n_rows))
-        state["final"] = finals
+            pending.append(gather_fused(f, sh, n_rows, async_op=True))          # users' gather runs under items' fusion
+        state["final"] = [fin() for _, fin in pending]
 
     def sync():
         torch.cuda.synchronize()

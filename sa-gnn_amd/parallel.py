@@ -93,21 +93,77 @@ def exchange_to_row_shards(local_out: torch.Tensor, sh: IntervalSharding, n_rows
     raise ValueError(f"unknown exchange mode {mode!r}")
 
 
-def gather_fused(final_local: torch.Tensor, sh: IntervalSharding, n_rows: int, group=None) -> torch.Tensor:
-    """All-gather of the fused embeddings: [rows_local, d] on each rank -> [N, d] everywhere."""
+class RowShardExchange:
+    """Incremental form of exchange_to_row_shards(mode="alltoall"): round j is posted as soon as
+    the rank's j-th interval output exists (async collective on RCCL's own stream), so it moves
+    over xGMI while the SpMM stack of interval j+1 runs; finish() makes the current stream wait for
+    every posted round and returns x [T, rows_local, d]."""
+
+    def __init__(self, sh: IntervalSharding, n_rows: int, d: int, device, dtype=torch.float32, group=None):
+        self.sh, self.n_rows, self.d, self.group = sh, int(n_rows), int(d), group
+        self.bounds = sh.row_bounds(n_rows)
+        lo, hi = self.bounds[sh.rank], self.bounds[sh.rank + 1]
+        self.rows_local = hi - lo
+        self.x = torch.empty((sh.T, self.rows_local, d), dtype=dtype, device=device)
+        self._empty = torch.empty((0, d), dtype=dtype, device=device)
+        self._work = []
+        self._posted = 0
+
+    def post(self, out_j: torch.Tensor | None):
+        """out_j [N, d]: this rank's next interval output (None when the rank has no interval in
+        this round — it still takes part in the collective with empty sends)."""
+        sh, j = self.sh, self._posted
+        self._posted += 1
+        if sh.world == 1:
+            self.x[j].copy_(out_j[self.bounds[0]:self.bounds[1]])
+            return
+        have = out_j is not None
+        cnt = min(sh.world, sh.T - j * sh.world)
+        out_splits = [self.rows_local if s < cnt else 0 for s in range(sh.world)]
+        in_splits = [self.bounds[r + 1] - self.bounds[r] for r in range(sh.world)] if have else [0] * sh.world
+        recv = self.x[j * sh.world: j * sh.world + cnt].view(cnt * self.rows_local, self.d)
+        w = dist.all_to_all_single(recv, out_j if have else self._empty, output_split_sizes=out_splits,
+                                   input_split_sizes=in_splits, group=self.group, async_op=True)
+        self._work.append(w)
+
+    def finish(self) -> torch.Tensor:
+        while self._posted < self.sh.rounds:       # rounds this rank never had an interval for
+            self.post(None)
+        for w in self._work:
+            w.wait()
+        self._work.clear()
+        self._posted = 0
+        return self.x
+
+
+def gather_fused(final_local: torch.Tensor, sh: IntervalSharding, n_rows: int, group=None,
+                 async_op: bool = False):
+    """All-gather of the fused embeddings: [rows_local, d] on each rank -> [N, d] everywhere.
+    With async_op=True returns (out, finish) — call finish() before reading `out`; the collective
+    runs on RCCL's stream meanwhile (e.g. under the other node type's fusion)."""
     d = final_local.shape[-1]
     if sh.world == 1:
-        return final_local
+        return (final_local, lambda: final_local) if async_op else final_local
     out = torch.empty((n_rows, d), dtype=final_local.dtype, device=final_local.device)
     bounds = sh.row_bounds(n_rows)
     if n_rows % sh.world == 0:
-        dist.all_gather_into_tensor(out, final_local.contiguous(), group=group)
+        work = dist.all_gather_into_tensor(out, final_local.contiguous(), group=group, async_op=True)
+
+        def finish():
+            work.wait()
+            return out
     else:                                                  # pad every shard to the largest one
         rmax = bounds[1] - bounds[0]
         mine = final_local.new_zeros((rmax, d))
         mine[: final_local.shape[0]] = final_local
         full = final_local.new_empty((sh.world * rmax, d))
-        dist.all_gather_into_tensor(full, mine, group=group)
-        for r in range(sh.world):
-            out[bounds[r]:bounds[r + 1]] = full[r * rmax: r * rmax + bounds[r + 1] - bounds[r]]
-    return out
+        work = dist.all_gather_into_tensor(full, mine, group=group, async_op=True)
+
+        def finish():
+            work.wait()
+            for r in range(sh.world):
+                out[bounds[r]:bounds[r + 1]] = full[r * rmax: r * rmax + bounds[r + 1] - bounds[r]]
+            return out
+    if async_op:
+        return out, finish
+    return finish()

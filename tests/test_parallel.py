@@ -13,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import selfgnn_oracle as O
-from sa_gnn_amd.parallel import IntervalSharding, exchange_to_row_shards, gather_fused
+from sa_gnn_amd.parallel import IntervalSharding, RowShardExchange, exchange_to_row_shards, gather_fused
 
 
 def _problem(T, U, I, d, seed=3):
@@ -38,7 +38,13 @@ def _worker(rank, world, port, T, mode, q):
                                   O.trans_to_lsts(O.transpose(mats[k]))[0], 2, 0.5)
             outs_u.append(u)
         local = torch.from_numpy(np.stack(outs_u, 0)) if outs_u else torch.empty((0, U, d))
-        x = exchange_to_row_shards(local, sh, U, mode=mode)          # [T, rows_local, d]
+        if mode == "incremental":                                    # async rounds, posted one by one
+            ex = RowShardExchange(sh, U, d, torch.device("cpu"))
+            for j in range(local.shape[0]):
+                ex.post(local[j])
+            x = ex.finish()
+        else:
+            x = exchange_to_row_shards(local, sh, U, mode=mode)      # [T, rows_local, d]
         lo, hi = sh.row_range(U)
         assert x.shape == (T, hi - lo, d)
         fused = O.interval_fusion(x.permute(1, 0, 2).numpy(), p, 4)
@@ -55,7 +61,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,T,mode", [(2, 4, "alltoall"), (2, 3, "alltoall"), (3, 4, "alltoall"),
-                                          (2, 1, "alltoall"), (2, 3, "allgather")])
+                                          (2, 1, "alltoall"), (2, 3, "allgather"), (2, 3, "incremental"),
+                                          (3, 7, "incremental")])
 def test_interval_sharded_pipeline_matches_single_process(world, T, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
