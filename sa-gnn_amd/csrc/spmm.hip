@@ -256,8 +256,10 @@ struct sagnn_spmm_plan {
 
 namespace {
 constexpr int kDefaultShort = 16;
-constexpr int kDefaultLong = 2048;
-constexpr int kDefaultChunk = 1024;
+// measured on MI355X: 256/256 beats 2048/1024 on small graphs (a 2k-edge row is
+// a 60-100 us serial chain for one wave) and is on par at 100M edges
+constexpr int kDefaultLong = 256;
+constexpr int kDefaultChunk = 256;
 
 int check_rowptr(const int32_t* rp, int64_t n_rows, int64_t nnz) {
   if (rp[0] != 0) return sagnn::fail(SAGNN_ERR_CSR, "rowptr[0] = %d, expected 0", rp[0]);
@@ -294,7 +296,8 @@ extern "C" int sagnn_spmm_plan_create(const int32_t* h_rowptr, const int32_t* d_
   if (!h_rowptr) return sagnn::fail(SAGNN_ERR_NULL, "h_rowptr is NULL");
   if ((d_rowptr == nullptr) != (d_colidx == nullptr) && nnz > 0)
     return sagnn::fail(SAGNN_ERR_NULL, "d_rowptr and d_colidx must both be given or both NULL");
-  if (n_rows < 0 || n_src < 0 || nnz < 0 || nnz > INT32_MAX || n_rows >= INT32_MAX ||
+  // edge cursors advance in steps of 64 past the last edge, so keep that much int32 headroom
+  if (n_rows < 0 || n_src < 0 || nnz < 0 || nnz > INT32_MAX - 256 || n_rows >= INT32_MAX - 256 ||
       n_src > INT32_MAX)
     return sagnn::fail(SAGNN_ERR_ARG, "CSR sizes out of int32 range");
   if (int rc = check_rowptr(h_rowptr, n_rows, nnz)) return rc;

@@ -54,3 +54,24 @@ def test_recommender_hot_path_vs_oracle(dev):
     np.testing.assert_allclose(y.cpu().numpy(), want, rtol=1e-4, atol=1e-5)
     with pytest.raises(ValueError):
         rec.messagePropagate(NNs.params["iEmbed"][0], rec.subAdj[0], "item")
+
+
+def test_graph_replay_matches_eager(dev):
+    """hipGraph capture of the whole hot path: replays track parameter updates and match eager."""
+    from sa_gnn_amd import synthetic
+    from sa_gnn_amd.DataHandler import DataHandler
+    from sa_gnn_amd.Params import args
+    from sa_gnn_amd.Utils import NNLayers as NNs
+    from sa_gnn_amd.model import Recommender
+    args.graphNum, args.gnn_layer, args.latdim, args.leaky = 3, 2, 64, 0.5
+    tmt = synthetic.make_trn_mat_time(400, 300, [3000, 2500, 2800])
+    rec = Recommender(dev, DataHandler.from_memory(tmt, synthetic.make_sequence(tmt)))
+    rec.prepareModel()
+    replay = rec.capture_forward()
+    with torch.no_grad():
+        NNs.params["uEmbed"].mul_(25)
+        NNs.params["iEmbed"].mul_(25)
+    fu_g, fi_g = (t.clone() for t in replay())
+    fu_e, fi_e = rec.forward()
+    torch.testing.assert_close(fu_g, fu_e, rtol=0, atol=0)
+    torch.testing.assert_close(fi_g, fi_e, rtol=0, atol=0)

@@ -58,7 +58,9 @@ def test_plan_chunking_host_only():
     deg[300] = 2048          # == long_thresh: stays a medium row
     rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int32)
     colidx = np.zeros(rowptr[-1], np.int32)
-    plan = SpmmPlan(rowptr, colidx, 500, 1)
+    dflt = SpmmPlan(rowptr, colidx, 500, 1).info
+    assert (dflt.short_thresh, dflt.long_thresh, dflt.chunk_edges) == (16, 256, 256)
+    plan = SpmmPlan(rowptr, colidx, 500, 1, tuning=(16, 2048, 1024))
     info = plan.info
     assert (info.short_thresh, info.long_thresh, info.chunk_edges) == (16, 2048, 1024)
     assert info.on_device == 0 and info.max_degree == 130000
