@@ -7,7 +7,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsagnn.so")
+# SAGNN_LIB points at an alternative build (diagnostic variants under scratch/); default: in-tree
+LIB_PATH = os.environ.get("SAGNN_LIB") or os.path.join(_HERE, "lib", "libsagnn.so")
 
 
 class SagnnError(RuntimeError):

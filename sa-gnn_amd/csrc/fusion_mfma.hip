@@ -14,6 +14,35 @@
 //   A-layout read (lane = row) bank-conflict free.
 #include "common.h"
 
+// Diagnostic build only (-DSAGNN_STAMPS): per-section cycle sums of the attention kernel, read back
+// with sagnn_debug_read_stamps(). Never compiled into the shipped library.
+#ifdef SAGNN_STAMPS
+__device__ unsigned long long g_stamps[8];
+#define STAMP_DECL unsigned long long st_prev = stamp_now(), st_acc[6] = {0, 0, 0, 0, 0, 0}
+#define STAMP(i)                         \
+  do {                                   \
+    const unsigned long long _t = stamp_now(); \
+    st_acc[i] += _t - st_prev;           \
+    st_prev = _t;                        \
+  } while (0)
+#define STAMP_FLUSH                                                        \
+  do {                                                                     \
+    if ((threadIdx.x & 63) == 0)                                           \
+      for (int _i = 0; _i < 6; ++_i) atomicAdd(&g_stamps[_i], st_acc[_i]); \
+  } while (0)
+__device__ __forceinline__ unsigned long long stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -227,6 +256,131 @@ __device__ __forceinline__ float head_sum(float p, int dk) {
   return p;
 }
 
+// Attention + mean over queries from the per-wave Q|K|V tile (row m = nb*t + ts, row stride QS,
+// Q at +0, K at +D, V at +2D). Generic form: lane = feature column; every (tq, s) score is
+// reduced across the dk lanes of the head, so each head's exp/normalise work is repeated dk times.
+template <int D, int QS>
+__device__ __forceinline__ void attention_columns(const float* __restrict__ qkv, int t, int dk,
+                                                  int nb_per_wave, int lane, float scale, float inv_t,
+                                                  int64_t node0, int64_t n, float* __restrict__ out,
+                                                  int64_t ld_out) {
+  constexpr int NPP = kWave / D;
+  constexpr int NPAR = 4;
+  const int col = lane % D;
+  const int sub = lane / D;
+  for (int nb0 = 0; nb0 < nb_per_wave; nb0 += NPP * NPAR) {
+    const float* base[NPAR];
+    float o[NPAR];
+    bool live[NPAR];
+#pragma unroll
+    for (int u = 0; u < NPAR; ++u) {
+      const int nb = nb0 + u * NPP + sub;
+      live[u] = nb < nb_per_wave;
+      base[u] = qkv + (live[u] ? nb : 0) * t * QS + col;
+      o[u] = 0.f;
+    }
+    for (int tq = 0; tq < t; ++tq) {
+      float qv[NPAR], rs[NPAR], ctx[NPAR];
+#pragma unroll
+      for (int u = 0; u < NPAR; ++u) {
+        qv[u] = base[u][tq * QS];
+        rs[u] = 0.f;
+        ctx[u] = 0.f;
+      }
+      for (int s = 0; s < t; ++s) {
+        float p[NPAR], vv[NPAR];
+#pragma unroll
+        for (int u = 0; u < NPAR; ++u) {
+          p[u] = qv[u] * base[u][s * QS + D];
+          vv[u] = base[u][s * QS + 2 * D];
+        }
+#pragma unroll
+        for (int u = 0; u < NPAR; ++u) p[u] = head_sum(p[u], dk);
+#pragma unroll
+        for (int u = 0; u < NPAR; ++u) {
+          const float e = __expf(p[u] * scale);
+          rs[u] += e;
+          ctx[u] = fmaf(e, vv[u], ctx[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NPAR; ++u) o[u] = fmaf(ctx[u], __builtin_amdgcn_rcpf(rs[u] + 1e-8f), o[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NPAR; ++u) {
+      const int64_t node = node0 + nb0 + u * NPP + sub;
+      if (live[u] && node < n) out[node * ld_out + col] = o[u] * inv_t;
+    }
+  }
+}
+
+// Head form for d_k = DK in {2, 4}: the DK lanes of a head split the KEY positions (lane c takes
+// s = c, c+DK, ...), each computing whole d_k-wide dot products and context vectors from vector
+// LDS reads; one DPP reduction of the row sum per query and one of the context per node. Per
+// node this is ~T^2/DK score evaluations per lane instead of T^2.
+template <int D, int DK, int QS, int NPAR>
+__device__ __forceinline__ void attention_heads(const float* __restrict__ qkv, int t, int nb_per_wave,
+                                                int lane, float scale, float inv_t, int64_t node0,
+                                                int64_t n, float* __restrict__ out, int64_t ld_out) {
+  constexpr int NPP = kWave / D;
+  typedef float vec __attribute__((ext_vector_type(DK)));
+  const int col = lane % D;
+  const int sub = lane / D;
+  const int c = col % DK;
+  const int h0 = col - c;
+  for (int nb0 = 0; nb0 < nb_per_wave; nb0 += NPP * NPAR) {
+    const float* base[NPAR];
+    bool live[NPAR];
+    vec o[NPAR];
+#pragma unroll
+    for (int u = 0; u < NPAR; ++u) {
+      const int nb = nb0 + u * NPP + sub;
+      live[u] = nb < nb_per_wave;
+      base[u] = qkv + (live[u] ? nb : 0) * t * QS + h0;
+      o[u] = (vec)(0.f);
+    }
+    for (int tq = 0; tq < t; ++tq) {
+      vec qv[NPAR], ctx[NPAR];
+      float rs[NPAR];
+#pragma unroll
+      for (int u = 0; u < NPAR; ++u) {
+        qv[u] = *reinterpret_cast<const vec*>(base[u] + tq * QS) * scale;
+        ctx[u] = (vec)(0.f);
+        rs[u] = 0.f;
+      }
+      for (int s = c; s < t; s += DK) {
+#pragma unroll
+        for (int u = 0; u < NPAR; ++u) {
+          const vec kv = *reinterpret_cast<const vec*>(base[u] + s * QS + D);
+          const vec vv = *reinterpret_cast<const vec*>(base[u] + s * QS + 2 * D);
+          float p = qv[u][0] * kv[0];
+#pragma unroll
+          for (int k = 1; k < DK; ++k) p = fmaf(qv[u][k], kv[k], p);
+          const float e = __expf(p);
+          rs[u] += e;
+          ctx[u] += e * vv;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NPAR; ++u) {
+        const float inv = __builtin_amdgcn_rcpf(head_sum(rs[u], DK) + 1e-8f);
+        o[u] += ctx[u] * inv;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NPAR; ++u) {
+      float r = 0.f;
+#pragma unroll
+      for (int k = 0; k < DK; ++k) {
+        const float tot = head_sum(o[u][k], DK);
+        r = (c == k) ? tot : r;
+      }
+      const int64_t node = node0 + nb0 + u * NPP + sub;
+      if (live[u] && node < n) out[node * ld_out + col] = r * inv_t;
+    }
+  }
+}
+
 template <int TM>
 __device__ __forceinline__ void load_square_fragments(float* __restrict__ Wf,
                                                       const float* __restrict__ W, int D) {
@@ -252,8 +406,7 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
   constexpr int LPR = D / 4;
   constexpr int RPI = kWave / LPR;
   constexpr int NFILL = kRowsPerWave / RPI;
-  constexpr int QS = 3 * D;        // row stride of the per-wave Q|K|V tile
-  constexpr int NPP = kWave / D;   // nodes per attention pass (1 at D=64, 2 at D=32)
+  constexpr int QS = 3 * D + 4;    // row stride of the per-wave Q|K|V tile (+16 B: rows of one head on distinct banks)
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Wqf = lds;
@@ -293,28 +446,44 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
     bvc[e] = bv[e * 32 + cj];
   }
 
+  float4 xr[NFILL];
+  auto fetch_tile = [&](int64_t tile) {
+    const int64_t node0 = (tile * 4 + wave) * nb_per_wave;
+#pragma unroll
+    for (int q = 0; q < NFILL; ++q) {
+      const int m = q * RPI + fr;
+      const int nb = m / t, ts = m - nb * t;
+      const int64_t node = node0 + nb;
+      xr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tile < n_tiles && m < rows_used && node < n)
+        xr[q] = *reinterpret_cast<const float4*>(x + node * ld_n + (int64_t)ts * ld_t + fc4);
+    }
+  };
+  fetch_tile(blockIdx.x);
+
+  STAMP_DECL;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t node0 = (tile * 4 + wave) * nb_per_wave;
-    if (node0 >= n) continue;  // wave-uniform
+    if (node0 >= n) {  // wave-uniform; keep the prefetch chain going for later tiles
+      fetch_tile(tile + gridDim.x);
+      continue;
+    }
+    STAMP(5);
     int ai_ = ai, kh_ = kh, cj_ = cj, rh_ = rh, fr_ = fr, fc4_ = fc4;
     asm volatile("" : "+v"(ai_), "+v"(kh_), "+v"(cj_), "+v"(rh_), "+v"(fr_), "+v"(fc4_));
 
-    // ---- fill the [32][D] tile: row m = nb*t + ts ------------------------------------------
+    // ---- fill the [32][D] tile: row m = nb*t + ts. xr was fetched one tile ahead -----------
 #pragma unroll
     for (int q = 0; q < NFILL; ++q) {
       const int m = q * RPI + fr_;
-      const int nb = m / t, ts = m - nb * t;
-      const int64_t node = node0 + nb;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < rows_used && node < n)
-        v = *reinterpret_cast<const float4*>(x + node * ld_n + (int64_t)ts * ld_t + fc4_);
       const int sw = m & 31;
       float* dst = stage + m * D;
-      dst[(fc4_ + 0) ^ sw] = v.x;
-      dst[(fc4_ + 1) ^ sw] = v.y;
-      dst[(fc4_ + 2) ^ sw] = v.z;
-      dst[(fc4_ + 3) ^ sw] = v.w;
+      dst[(fc4_ + 0) ^ sw] = xr[q].x;
+      dst[(fc4_ + 1) ^ sw] = xr[q].y;
+      dst[(fc4_ + 2) ^ sw] = xr[q].z;
+      dst[(fc4_ + 3) ^ sw] = xr[q].w;
     }
+    fetch_tile(tile + gridDim.x);  // next tile's rows, in flight under this tile's work
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -323,6 +492,7 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
     for (int kk = 0; kk < KS; ++kk) a[kk] = stage[ai_ * D + ((2 * kk + kh_) ^ ai_)];
     __builtin_amdgcn_wave_barrier();
 
+    STAMP(0);
     // ---- layer norm on the A operand: moments over the node's t rows x D columns ----------
     if (apply_ln) {
       const int base = (ai_ / t) * t;               // first row of this lane's node
@@ -350,6 +520,7 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
       }
     }
 
+    STAMP(1);
     // ---- Q | K | V = A @ W + b ---------------------------------------------------------------
     f32x16 aq[TM], ak[TM], av[TM];
 #pragma unroll
@@ -394,6 +565,7 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
       }
     }
 
+    STAMP(2);
     // ---- Q | K | V tile to LDS (C layout -> row major) --------------------------------------
 #pragma unroll
     for (int e = 0; e < TM; ++e)
@@ -408,58 +580,23 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- attention per node and head, lane = feature column --------------------------------
-    // NPAR independent nodes are interleaved so their LDS reads, head reductions and exps
-    // overlap (one node's (tq, s) chain alone is latency-bound).
-    const int col = lane % D;
-    const int sub = lane / D;                       // node parity inside a pass (D = 32)
-    constexpr int NPAR = 4;
-    for (int nb0 = 0; nb0 < nb_per_wave; nb0 += NPP * NPAR) {
-      const float* base[NPAR];
-      float o[NPAR];
-      bool live[NPAR];
-#pragma unroll
-      for (int u = 0; u < NPAR; ++u) {
-        const int nb = nb0 + u * NPP + sub;
-        live[u] = nb < nb_per_wave;
-        base[u] = qkv + (live[u] ? nb : 0) * t * QS + col;
-        o[u] = 0.f;
-      }
-      for (int tq = 0; tq < t; ++tq) {
-        float qv[NPAR], rs[NPAR], ctx[NPAR];
-#pragma unroll
-        for (int u = 0; u < NPAR; ++u) {
-          qv[u] = base[u][tq * QS];
-          rs[u] = 0.f;
-          ctx[u] = 0.f;
-        }
-        for (int s = 0; s < t; ++s) {
-          float p[NPAR], vv[NPAR];
-#pragma unroll
-          for (int u = 0; u < NPAR; ++u) {
-            p[u] = qv[u] * base[u][s * QS + D];
-            vv[u] = base[u][s * QS + 2 * D];
-          }
-#pragma unroll
-          for (int u = 0; u < NPAR; ++u) p[u] = head_sum(p[u], dk);
-#pragma unroll
-          for (int u = 0; u < NPAR; ++u) {
-            const float e = __expf(p[u] * scale);
-            rs[u] += e;
-            ctx[u] = fmaf(e, vv[u], ctx[u]);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < NPAR; ++u) o[u] = fmaf(ctx[u], __builtin_amdgcn_rcpf(rs[u] + 1e-8f), o[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < NPAR; ++u) {
-        const int64_t node = node0 + nb0 + u * NPP + sub;
-        if (live[u] && node < n) out[node * ld_out + col] = o[u] * inv_t;
-      }
+    STAMP(3);
+    // ---- attention per node and head ---------------------------------------------------------
+    // NPAR nodes are interleaved for ILP; with few nodes per wave (large t) extra slots are waste
+    const bool wide = nb_per_wave >= 4 * (kWave / D);
+    if (dk == 4) {
+      if (wide) attention_heads<D, 4, QS, 4>(qkv, t, nb_per_wave, lane, scale, inv_t, node0, n, out, ld_out);
+      else attention_heads<D, 4, QS, 2>(qkv, t, nb_per_wave, lane, scale, inv_t, node0, n, out, ld_out);
+    } else if (dk == 2) {
+      if (wide) attention_heads<D, 2, QS, 4>(qkv, t, nb_per_wave, lane, scale, inv_t, node0, n, out, ld_out);
+      else attention_heads<D, 2, QS, 2>(qkv, t, nb_per_wave, lane, scale, inv_t, node0, n, out, ld_out);
+    } else {
+      attention_columns<D, QS>(qkv, t, dk, nb_per_wave, lane, scale, inv_t, node0, n, out, ld_out);
     }
     __builtin_amdgcn_wave_barrier();
+    STAMP(4);
   }
+  STAMP_FLUSH;
 }
 
 }  // namespace
@@ -512,7 +649,7 @@ static int launch_ln_mhsa(const float* x, int64_t ld_n, int64_t ld_t, int64_t n,
                           const float* gamma, const float* beta, float eps, int apply_ln,
                           const float* Wq, const float* bq, const float* Wk, const float* bk,
                           const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s) {
-  const size_t lds = (size_t)(3 * D * D + 4 * kRowsPerWave * 3 * D) * sizeof(float);
+  const size_t lds = (size_t)(3 * D * D + 4 * kRowsPerWave * (3 * D + 4)) * sizeof(float);
   static bool configured = false;
   if (!configured) {
     SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_mhsa_mean_mfma_kernel<D>),
@@ -548,3 +685,14 @@ int ln_mhsa_mean_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int
 }
 
 }  // namespace sagnn
+
+#ifdef SAGNN_STAMPS
+extern "C" int sagnn_debug_read_stamps(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
