@@ -141,6 +141,28 @@ int sagnn_spmm_f32(const sagnn_spmm_plan* plan, const float* X, int64_t ldx, int
                    const float* acc_in, int64_t ld_acc_in, float* acc_out, int64_t ld_acc_out,
                    void* workspace, size_t workspace_bytes, void* stream);
 
+/* Extended epilogue for training (sagnn_spmm_ex_f32); zero-initialise and fill what is used.
+ *   s = A·X;  y = max(leaky*s, s) + residual;  out = y;  acc_out = acc_in + y
+ *   mask_out [n_rows, d/4] bytes: bit j of byte l is 1 iff the activation passed s[4l+j] through
+ *       with slope 1 (tf.maximum(leaky*x, x) sends the gradient to its FIRST argument on ties,
+ *       so x = 0 counts as slope `leaky`: reference Utils/NNLayers.py:136)
+ *   out2 = v * (mask_in bit ? 1 : slope2), v = the accumulated value if acc_out is given, else y
+ *       (what the next backward step gathers). */
+typedef struct sagnn_spmm_epilogue {
+  float leaky;
+  const float* residual; int64_t ldr;
+  float* out; int64_t ldo;
+  const float* acc_in; int64_t ld_acc_in;
+  float* acc_out; int64_t ld_acc_out;
+  uint8_t* mask_out;
+  const uint8_t* mask_in;
+  float* out2; int64_t ldo2; float slope2;
+} sagnn_spmm_epilogue;
+
+int sagnn_spmm_ex_f32(const sagnn_spmm_plan* plan, const float* X, int64_t ldx, int d,
+                      const sagnn_spmm_epilogue* epilogue, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
 /* ------------------------------------------------------------------------------------
  * sagnn_gnn_interval_f32 — one iteration k of the loop model.py:118-129 (L layers, both
  * directions, simultaneous update, residuals, add_n), 2*L SpMM launches issued from C.
@@ -160,6 +182,26 @@ int sagnn_gnn_interval_f32(const sagnn_spmm_plan* plan_user, const sagnn_spmm_pl
                            int d, int n_layers, float leaky, float* scratch_u, float* scratch_i,
                            float* user_out, int64_t ld_uo, float* item_out, int64_t ld_io,
                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* Training form of sagnn_gnn_interval_f32: additionally records the activation masks of every
+ * layer, mask_u [n_layers, U, d/4] and mask_i [n_layers, I, d/4] bytes (both or neither). */
+int sagnn_gnn_interval_ex_f32(const sagnn_spmm_plan* plan_user, const sagnn_spmm_plan* plan_item,
+                              const float* u0, int64_t ld_u0, const float* i0, int64_t ld_i0, int d,
+                              int n_layers, float leaky, float* scratch_u, float* scratch_i,
+                              float* user_out, int64_t ld_uo, float* item_out, int64_t ld_io,
+                              uint8_t* mask_u, uint8_t* mask_i, void* workspace,
+                              size_t workspace_bytes, void* stream);
+
+/* Backward of the interval stack (what tf.gradients builds for model.py:118-129): given
+ * G_u = dL/d user_out, G_i = dL/d item_out and the recorded masks, writes dL/d u0 and dL/d i0.
+ * Same SpMM kernel with the roles of the two adjacencies swapped (the reference already holds
+ * both, model.py:234-236). scratch_u: [4, U, d] floats, scratch_i: [4, I, d] floats. */
+int sagnn_gnn_interval_bwd_f32(const sagnn_spmm_plan* plan_user, const sagnn_spmm_plan* plan_item,
+                               const float* G_u, int64_t ld_gu, const float* G_i, int64_t ld_gi, int d,
+                               int n_layers, float leaky, const uint8_t* mask_u, const uint8_t* mask_i,
+                               float* scratch_u, float* scratch_i, float* grad_u0, int64_t ld_du,
+                               float* grad_i0, int64_t ld_di, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Interval fusion (model.py:135-155). x[node, interval, :] is read at

@@ -251,3 +251,33 @@ def init_fusion_params(d: int, rng: np.random.Generator, dtype=np.float32) -> di
         "Wk": xavier_uniform((d, d), rng, dtype), "bk": (0.1 * rng.standard_normal(d)).astype(dtype),
         "Wv": xavier_uniform((d, d), rng, dtype), "bv": (0.1 * rng.standard_normal(d)).astype(dtype),
     }
+
+
+# ----------------------------------------------------------------------------------------------
+# Gradient oracle: the same path restated in differentiable torch (CPU, float64) so that
+# torch.autograd supplies what tf.gradients would (reference model.py:250 minimises the loss
+# through these ops). Test infrastructure only.
+# ----------------------------------------------------------------------------------------------
+
+
+def torch_message_propagate(srclats, indices, n_out: int, leaky: float):
+    """model.py:80-92 in torch: gather, sorted segment sum (index_add), zero-filled to n_out rows,
+    tf.maximum(leaky*x, x). On ties tf.maximum sends the gradient to its first argument
+    (MaximumGrad uses x >= y), restated with torch.where."""
+    import torch
+    idx = torch.as_tensor(indices, dtype=torch.long)
+    gathered = srclats.index_select(0, idx[:, 1])
+    lat = torch.zeros((n_out, srclats.shape[1]), dtype=srclats.dtype).index_add(0, idx[:, 0], gathered)
+    a = leaky * lat
+    return torch.where(a >= lat, a, lat)
+
+
+def torch_gnn_interval(u0, i0, adj_idx, tp_idx, n_layers: int, leaky: float):
+    """model.py:118-129 in torch (see gnn_interval above)."""
+    embs0, embs1 = [u0], [i0]
+    for _ in range(n_layers):
+        a0 = torch_message_propagate(embs1[-1], adj_idx, u0.shape[0], leaky)
+        a1 = torch_message_propagate(embs0[-1], tp_idx, i0.shape[0], leaky)
+        embs0.append(a0 + embs0[-1])
+        embs1.append(a1 + embs1[-1])
+    return sum(embs0[1:], embs0[0]), sum(embs1[1:], embs1[0])

@@ -22,6 +22,13 @@ class Tuning(ctypes.Structure):
                 ("reserved", c_int32)]
 
 
+class SpmmEpilogue(ctypes.Structure):
+    _fields_ = [("leaky", c_float), ("residual", c_void_p), ("ldr", c_int64), ("out", c_void_p),
+                ("ldo", c_int64), ("acc_in", c_void_p), ("ld_acc_in", c_int64), ("acc_out", c_void_p),
+                ("ld_acc_out", c_int64), ("mask_out", c_void_p), ("mask_in", c_void_p),
+                ("out2", c_void_p), ("ldo2", c_int64), ("slope2", c_float)]
+
+
 class PlanInfo(ctypes.Structure):
     _fields_ = [("n_rows", c_int64), ("n_src", c_int64), ("nnz", c_int64),
                 ("n_long_rows", c_int64), ("n_chunks", c_int64), ("short_thresh", c_int32),
@@ -45,6 +52,14 @@ SIGNATURES = {
     "sagnn_spmm_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_int64, c_float,
                                c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                c_size_t, c_void_p]),
+    "sagnn_spmm_ex_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, POINTER(SpmmEpilogue), c_void_p, c_size_t,
+                                  c_void_p]),
+    "sagnn_gnn_interval_ex_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
+                                          c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sagnn_gnn_interval_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
+                                           c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                           c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "sagnn_gnn_interval_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                        c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),

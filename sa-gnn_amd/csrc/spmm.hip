@@ -39,6 +39,13 @@ struct Epilogue {
   float* acc_out;
   int64_t ld_acc_out;
   float leaky;
+  // training extras (sagnn_spmm_ex_f32)
+  uint8_t* mask_out;       // [n_rows, d/4]: bit j of byte l = 1 iff the activation passed s[4l+j] through
+  const uint8_t* mask_in;  // same layout, for out2
+  float* out2;             // out2 = v * (mask_in bit ? 1 : slope2), v = acc value if acc_out else y
+  int64_t ldo2;
+  float slope2;
+  int mask_stride;         // bytes per mask row (= lanes per row)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) {
@@ -52,13 +59,20 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) {
   a.w += b.w;
 }
 
-// y = max(leaky*s, s) + residual ; out = y ; acc_out = acc_in + y.
+// y = max(leaky*s, s) + residual ; out = y ; acc_out = acc_in + y ; training extras as above.
 __device__ __forceinline__ void finish_row(const Epilogue& ep, int64_t row, int col, float4 s) {
   float4 y;
   y.x = fmaxf(ep.leaky * s.x, s.x);
   y.y = fmaxf(ep.leaky * s.y, s.y);
   y.z = fmaxf(ep.leaky * s.z, s.z);
   y.w = fmaxf(ep.leaky * s.w, s.w);
+  if (ep.mask_out) {
+    // tf.maximum(leaky*x, x) routes the gradient to its FIRST argument on ties (x = 0), so the
+    // slope is 1 only where x is strictly the larger one
+    const unsigned bits = (s.x > ep.leaky * s.x ? 1u : 0u) | (s.y > ep.leaky * s.y ? 2u : 0u) |
+                          (s.z > ep.leaky * s.z ? 4u : 0u) | (s.w > ep.leaky * s.w ? 8u : 0u);
+    ep.mask_out[row * ep.mask_stride + (col >> 2)] = (uint8_t)bits;
+  }
   float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
   if (ep.residual) {
     r = ld4(ep.residual + row * ep.ldr + col);
@@ -74,7 +88,36 @@ __device__ __forceinline__ void finish_row(const Epilogue& ep, int64_t row, int 
     }
     add4(a, y);
     st4(ep.acc_out + row * ep.ld_acc_out + col, a);
+    y = a;
   }
+  if (ep.out2) {
+    const unsigned bits = ep.mask_in ? ep.mask_in[row * ep.mask_stride + (col >> 2)] : 15u;
+    float4 z;
+    z.x = (bits & 1u) ? y.x : ep.slope2 * y.x;
+    z.y = (bits & 2u) ? y.y : ep.slope2 * y.y;
+    z.z = (bits & 4u) ? y.z : ep.slope2 * y.z;
+    z.w = (bits & 8u) ? y.w : ep.slope2 * y.w;
+    st4(ep.out2 + row * ep.ldo2 + col, z);
+  }
+}
+
+// gm[r, :] = g[r, :] * (mask bit ? 1 : slope): seeds the backward chain of the GNN stack.
+__global__ void mask_scale_kernel(const float* __restrict__ g, int64_t ldg, const uint8_t* __restrict__ mask,
+                                  int mask_stride, float slope, float* __restrict__ gm, int64_t ldgm,
+                                  int64_t n_rows, int d) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lpr = d >> 2;
+  if (i >= n_rows * lpr) return;
+  const int64_t row = i / lpr;
+  const int l = (int)(i - row * lpr);
+  const float4 v = ld4(g + row * ldg + 4 * l);
+  const unsigned bits = mask[row * mask_stride + l];
+  float4 z;
+  z.x = (bits & 1u) ? v.x : slope * v.x;
+  z.y = (bits & 2u) ? v.y : slope * v.y;
+  z.z = (bits & 4u) ? v.z : slope * v.z;
+  z.w = (bits & 8u) ? v.w : slope * v.w;
+  st4(gm + row * ldgm + 4 * l, z);
 }
 
 // Whole wave sums X[idx[e], :] for e in [e0, e1): G neighbour rows per load instruction.
@@ -452,22 +495,22 @@ int check_mat(const char* name, const void* ptr, int64_t ld, int d, bool require
 
 }  // namespace
 
-extern "C" int sagnn_spmm_f32(const sagnn_spmm_plan* plan, const float* X, int64_t ldx, int d,
-                              const float* residual, int64_t ldr, float leaky, float* out,
-                              int64_t ldo, const float* acc_in, int64_t ld_acc_in, float* acc_out,
-                              int64_t ld_acc_out, void* workspace, size_t workspace_bytes,
-                              void* stream) {
-  if (!plan) return sagnn::fail(SAGNN_ERR_NULL, "plan is NULL");
+extern "C" int sagnn_spmm_ex_f32(const sagnn_spmm_plan* plan, const float* X, int64_t ldx, int d,
+                                 const sagnn_spmm_epilogue* e, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+  if (!plan || !e) return sagnn::fail(SAGNN_ERR_NULL, "plan/epilogue is NULL");
   if (!plan->info.on_device) return sagnn::fail(SAGNN_ERR_ARG, "plan was built host-only (no device CSR)");
   if (d < 4 || d > 256 || (d & 3)) return sagnn::fail(SAGNN_ERR_DIM, "d = %d: need a multiple of 4 in [4, 256]", d);
-  if (!out && !acc_out) return sagnn::fail(SAGNN_ERR_NULL, "both out and acc_out are NULL");
+  if (!e->out && !e->acc_out && !e->out2) return sagnn::fail(SAGNN_ERR_NULL, "no output given");
   if (int rc = check_mat("X", X, ldx, d, plan->info.nnz > 0)) return rc;
-  if (int rc = check_mat("residual", residual, ldr, d, false)) return rc;
-  if (int rc = check_mat("out", out, ldo, d, false)) return rc;
-  if (int rc = check_mat("acc_in", acc_in, ld_acc_in, d, false)) return rc;
-  if (int rc = check_mat("acc_out", acc_out, ld_acc_out, d, false)) return rc;
-  if ((out && out == X) || (acc_out && acc_out == X))
-    return sagnn::fail(SAGNN_ERR_ARG, "out/acc_out must not alias X");
+  if (int rc = check_mat("residual", e->residual, e->ldr, d, false)) return rc;
+  if (int rc = check_mat("out", e->out, e->ldo, d, false)) return rc;
+  if (int rc = check_mat("acc_in", e->acc_in, e->ld_acc_in, d, false)) return rc;
+  if (int rc = check_mat("acc_out", e->acc_out, e->ld_acc_out, d, false)) return rc;
+  if (int rc = check_mat("out2", e->out2, e->ldo2, d, false)) return rc;
+  if ((e->out && e->out == X) || (e->acc_out && e->acc_out == X) || (e->out2 && e->out2 == X))
+    return sagnn::fail(SAGNN_ERR_ARG, "outputs must not alias X");
+  if (e->mask_in && !e->out2) return sagnn::fail(SAGNN_ERR_ARG, "mask_in given without out2");
   const size_t need = sagnn_spmm_workspace_bytes(plan, d);
   if (need > 0) {
     if (!workspace || workspace_bytes < need)
@@ -477,7 +520,8 @@ extern "C" int sagnn_spmm_f32(const sagnn_spmm_plan* plan, const float* X, int64
   }
   if (plan->info.n_rows == 0) return SAGNN_OK;
 
-  Epilogue ep{residual, ldr, acc_in, ld_acc_in, out, ldo, acc_out, ld_acc_out, leaky};
+  Epilogue ep{e->residual, e->ldr,       e->acc_in,  e->ld_acc_in, e->out,   e->ldo,    e->acc_out, e->ld_acc_out,
+              e->leaky,    e->mask_out,  e->mask_in, e->out2,      e->ldo2,  e->slope2, d / 4};
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(workspace);
   switch (sagnn::lanes_per_row(d)) {
@@ -488,20 +532,46 @@ extern "C" int sagnn_spmm_f32(const sagnn_spmm_plan* plan, const float* X, int64
   }
 }
 
-extern "C" int sagnn_gnn_interval_f32(const sagnn_spmm_plan* plan_user,
-                                      const sagnn_spmm_plan* plan_item, const float* u0,
-                                      int64_t ld_u0, const float* i0, int64_t ld_i0, int d,
-                                      int n_layers, float leaky, float* scratch_u, float* scratch_i,
-                                      float* user_out, int64_t ld_uo, float* item_out, int64_t ld_io,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
-  if (!plan_user || !plan_item) return sagnn::fail(SAGNN_ERR_NULL, "plan is NULL");
+extern "C" int sagnn_spmm_f32(const sagnn_spmm_plan* plan, const float* X, int64_t ldx, int d,
+                              const float* residual, int64_t ldr, float leaky, float* out,
+                              int64_t ldo, const float* acc_in, int64_t ld_acc_in, float* acc_out,
+                              int64_t ld_acc_out, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  sagnn_spmm_epilogue e{};
+  e.leaky = leaky;
+  e.residual = residual;
+  e.ldr = ldr;
+  e.out = out;
+  e.ldo = ldo;
+  e.acc_in = acc_in;
+  e.ld_acc_in = ld_acc_in;
+  e.acc_out = acc_out;
+  e.ld_acc_out = ld_acc_out;
+  return sagnn_spmm_ex_f32(plan, X, ldx, d, &e, workspace, workspace_bytes, stream);
+}
+
+namespace {
+int check_interval_plans(const sagnn_spmm_plan* pu, const sagnn_spmm_plan* pi) {
+  if (!pu || !pi) return sagnn::fail(SAGNN_ERR_NULL, "plan is NULL");
+  if (pu->info.n_src != pi->info.n_rows || pi->info.n_src != pu->info.n_rows)
+    return sagnn::fail(SAGNN_ERR_ARG, "plans are not a transposed pair: user %lldx%lld, item %lldx%lld",
+                       (long long)pu->info.n_rows, (long long)pu->info.n_src, (long long)pi->info.n_rows,
+                       (long long)pi->info.n_src);
+  return SAGNN_OK;
+}
+}  // namespace
+
+extern "C" int sagnn_gnn_interval_ex_f32(const sagnn_spmm_plan* plan_user, const sagnn_spmm_plan* plan_item,
+                                         const float* u0, int64_t ld_u0, const float* i0, int64_t ld_i0,
+                                         int d, int n_layers, float leaky, float* scratch_u,
+                                         float* scratch_i, float* user_out, int64_t ld_uo, float* item_out,
+                                         int64_t ld_io, uint8_t* mask_u, uint8_t* mask_i, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  if (int rc = check_interval_plans(plan_user, plan_item)) return rc;
   if (!u0 || !i0 || !user_out || !item_out) return sagnn::fail(SAGNN_ERR_NULL, "null embedding pointer");
   if (n_layers < 1) return sagnn::fail(SAGNN_ERR_ARG, "n_layers = %d: need >= 1", n_layers);
+  if ((mask_u == nullptr) != (mask_i == nullptr)) return sagnn::fail(SAGNN_ERR_NULL, "give both masks or neither");
   const int64_t U = plan_user->info.n_rows, I = plan_item->info.n_rows;
-  if (plan_user->info.n_src != I || plan_item->info.n_src != U)
-    return sagnn::fail(SAGNN_ERR_ARG, "plans are not a transposed pair: user %lldx%lld, item %lldx%lld",
-                       (long long)U, (long long)plan_user->info.n_src, (long long)I,
-                       (long long)plan_item->info.n_src);
   if (n_layers > 1 && (!scratch_u || !scratch_i))
     return sagnn::fail(SAGNN_ERR_NULL, "scratch buffers required for n_layers > 1");
   // e^l lives in cur; layer l writes e^{l+1} into the other half of the ping-pong scratch
@@ -510,25 +580,131 @@ extern "C" int sagnn_gnn_interval_f32(const sagnn_spmm_plan* plan_user,
   int64_t lcu = ld_u0;
   const float* ci = i0;
   int64_t lci = ld_i0;
+  const int64_t mrow = d / 4;
   for (int l = 0; l < n_layers; ++l) {
     const bool last = (l + 1 == n_layers);
-    float* nu = last ? nullptr : scratch_u + (int64_t)(l & 1) * U * d;
-    float* ni = last ? nullptr : scratch_i + (int64_t)(l & 1) * I * d;
+    sagnn_spmm_epilogue eu{}, ei{};
+    eu.leaky = ei.leaky = leaky;
+    eu.residual = cu;
+    eu.ldr = lcu;
+    ei.residual = ci;
+    ei.ldr = lci;
+    eu.out = last ? nullptr : scratch_u + (int64_t)(l & 1) * U * d;
+    ei.out = last ? nullptr : scratch_i + (int64_t)(l & 1) * I * d;
+    eu.ldo = ei.ldo = d;
     // layer 0 seeds the running sum with e^0 (acc_in = residual); later layers add in place.
-    const float* au = (l == 0) ? cu : user_out;
-    const int64_t lau = (l == 0) ? lcu : ld_uo;
-    const float* ai = (l == 0) ? ci : item_out;
-    const int64_t lai = (l == 0) ? lci : ld_io;
-    if (int rc = sagnn_spmm_f32(plan_user, ci, lci, d, cu, lcu, leaky, nu, d, au, lau, user_out,
-                                ld_uo, workspace, workspace_bytes, stream))
-      return rc;
-    if (int rc = sagnn_spmm_f32(plan_item, cu, lcu, d, ci, lci, leaky, ni, d, ai, lai, item_out,
-                                ld_io, workspace, workspace_bytes, stream))
-      return rc;
-    cu = nu;
+    eu.acc_in = (l == 0) ? cu : user_out;
+    eu.ld_acc_in = (l == 0) ? lcu : ld_uo;
+    ei.acc_in = (l == 0) ? ci : item_out;
+    ei.ld_acc_in = (l == 0) ? lci : ld_io;
+    eu.acc_out = user_out;
+    eu.ld_acc_out = ld_uo;
+    ei.acc_out = item_out;
+    ei.ld_acc_out = ld_io;
+    if (mask_u) {
+      eu.mask_out = mask_u + (int64_t)l * U * mrow;
+      ei.mask_out = mask_i + (int64_t)l * I * mrow;
+    }
+    if (int rc = sagnn_spmm_ex_f32(plan_user, ci, lci, d, &eu, workspace, workspace_bytes, stream)) return rc;
+    if (int rc = sagnn_spmm_ex_f32(plan_item, cu, lcu, d, &ei, workspace, workspace_bytes, stream)) return rc;
+    cu = eu.out;
     lcu = d;
-    ci = ni;
+    ci = ei.out;
     lci = d;
+  }
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_gnn_interval_f32(const sagnn_spmm_plan* plan_user,
+                                      const sagnn_spmm_plan* plan_item, const float* u0,
+                                      int64_t ld_u0, const float* i0, int64_t ld_i0, int d,
+                                      int n_layers, float leaky, float* scratch_u, float* scratch_i,
+                                      float* user_out, int64_t ld_uo, float* item_out, int64_t ld_io,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  return sagnn_gnn_interval_ex_f32(plan_user, plan_item, u0, ld_u0, i0, ld_i0, d, n_layers, leaky, scratch_u,
+                                   scratch_i, user_out, ld_uo, item_out, ld_io, nullptr, nullptr, workspace,
+                                   workspace_bytes, stream);
+}
+
+// Backward of sagnn_gnn_interval_ex_f32. With g^l = dL/de^l (l = 0..L), G = dL/d(sum_l e^l):
+//   g_u^L = G_u,  g_i^L = G_i
+//   g_u^l = G_u + g_u^{l+1} + A   (g_i^{l+1} * m_i^{l+1})     (plan_user: rows = users)
+//   g_i^l = G_i + g_i^{l+1} + A^T (g_u^{l+1} * m_u^{l+1})     (plan_item: rows = items)
+// m^{l+1} = slope mask of the forward layer that produced e^{l+1} (1 where the activation passed
+// the sum through, leaky elsewhere). Each step is the forward kernel with slope 1, residual =
+// g^{l+1}, acc_in = G, and the masked copy for the next step written by the same epilogue.
+extern "C" int sagnn_gnn_interval_bwd_f32(const sagnn_spmm_plan* plan_user, const sagnn_spmm_plan* plan_item,
+                                          const float* G_u, int64_t ld_gu, const float* G_i, int64_t ld_gi,
+                                          int d, int n_layers, float leaky, const uint8_t* mask_u,
+                                          const uint8_t* mask_i, float* scratch_u, float* scratch_i,
+                                          float* grad_u0, int64_t ld_du, float* grad_i0, int64_t ld_di,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_interval_plans(plan_user, plan_item)) return rc;
+  if (!G_u || !G_i || !grad_u0 || !grad_i0 || !mask_u || !mask_i || !scratch_u || !scratch_i)
+    return sagnn::fail(SAGNN_ERR_NULL, "null pointer");
+  if (n_layers < 1) return sagnn::fail(SAGNN_ERR_ARG, "n_layers = %d: need >= 1", n_layers);
+  if (d < 4 || d > 256 || (d & 3)) return sagnn::fail(SAGNN_ERR_DIM, "d = %d: need a multiple of 4 in [4, 256]", d);
+  if (int rc = check_mat("G_u", G_u, ld_gu, d, true)) return rc;
+  if (int rc = check_mat("G_i", G_i, ld_gi, d, true)) return rc;
+  const int64_t U = plan_user->info.n_rows, I = plan_item->info.n_rows;
+  const int64_t mrow = d / 4;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // scratch_x: [4][N][d]: slots 0/1 ping-pong the full gradients g^l, slots 2/3 the masked copies
+  float* gfull_u[2] = {scratch_u, scratch_u + U * d};
+  float* gmask_u[2] = {scratch_u + 2 * U * d, scratch_u + 3 * U * d};
+  float* gfull_i[2] = {scratch_i, scratch_i + I * d};
+  float* gmask_i[2] = {scratch_i + 2 * I * d, scratch_i + 3 * I * d};
+  // seed: g^L * m^L
+  {
+    const int threads = 256;
+    const int64_t nu = U * mrow, ni = I * mrow;
+    if (nu > 0) {
+      hipLaunchKernelGGL(mask_scale_kernel, dim3((unsigned)((nu + threads - 1) / threads)), dim3(threads), 0, s, G_u,
+                         ld_gu, mask_u + (int64_t)(n_layers - 1) * U * mrow, (int)mrow, leaky, gmask_u[0], (int64_t)d, U, d);
+      SAGNN_HIP_TRY(hipGetLastError());
+    }
+    if (ni > 0) {
+      hipLaunchKernelGGL(mask_scale_kernel, dim3((unsigned)((ni + threads - 1) / threads)), dim3(threads), 0, s, G_i,
+                         ld_gi, mask_i + (int64_t)(n_layers - 1) * I * mrow, (int)mrow, leaky, gmask_i[0], (int64_t)d, I, d);
+      SAGNN_HIP_TRY(hipGetLastError());
+    }
+  }
+  const float* gu_next = G_u;  // g^{l+1}
+  int64_t ld_gun = ld_gu;
+  const float* gi_next = G_i;
+  int64_t ld_gin = ld_gi;
+  int cur = 0;  // index of the masked buffers holding g^{l+1} * m^{l+1}
+  for (int l = n_layers - 1; l >= 0; --l) {
+    const bool final_step = (l == 0);
+    sagnn_spmm_epilogue eu{}, ei{};
+    eu.leaky = ei.leaky = 1.f;
+    eu.residual = gu_next;
+    eu.ldr = ld_gun;
+    ei.residual = gi_next;
+    ei.ldr = ld_gin;
+    eu.acc_in = G_u;
+    eu.ld_acc_in = ld_gu;
+    ei.acc_in = G_i;
+    ei.ld_acc_in = ld_gi;
+    eu.acc_out = final_step ? grad_u0 : gfull_u[l & 1];
+    eu.ld_acc_out = final_step ? ld_du : d;
+    ei.acc_out = final_step ? grad_i0 : gfull_i[l & 1];
+    ei.ld_acc_out = final_step ? ld_di : d;
+    if (!final_step) {
+      eu.mask_in = mask_u + (int64_t)(l - 1) * U * mrow;
+      ei.mask_in = mask_i + (int64_t)(l - 1) * I * mrow;
+      eu.out2 = gmask_u[cur ^ 1];
+      ei.out2 = gmask_i[cur ^ 1];
+      eu.ldo2 = ei.ldo2 = d;
+      eu.slope2 = ei.slope2 = leaky;
+    }
+    if (int rc = sagnn_spmm_ex_f32(plan_user, gmask_i[cur], d, d, &eu, workspace, workspace_bytes, stream)) return rc;
+    if (int rc = sagnn_spmm_ex_f32(plan_item, gmask_u[cur], d, d, &ei, workspace, workspace_bytes, stream)) return rc;
+    gu_next = eu.acc_out;
+    ld_gun = eu.ld_acc_out;
+    gi_next = ei.acc_out;
+    ld_gin = ei.ld_acc_out;
+    cur ^= 1;
   }
   return SAGNN_OK;
 }

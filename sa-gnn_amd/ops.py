@@ -138,11 +138,19 @@ def spmm(plan: SpmmPlan, x: torch.Tensor, leaky: float, residual: torch.Tensor |
     return out
 
 
+def _interval_ws(plan_user: SpmmPlan, plan_item: SpmmPlan, d: int):
+    wu, wi = plan_user.workspace(d), plan_item.workspace(d)
+    return wu if (wi is None or (wu is not None and wu.numel() >= wi.numel())) else wi
+
+
 def gnn_interval(plan_user: SpmmPlan, plan_item: SpmmPlan, u0: torch.Tensor, i0: torch.Tensor,
                  n_layers: int, leaky: float, user_out: torch.Tensor, item_out: torch.Tensor,
-                 scratch_u: torch.Tensor | None = None, scratch_i: torch.Tensor | None = None):
-    """One interval of the GNN loop (reference model.py:118-129): sagnn_gnn_interval_f32.
-    user_out / item_out are [rows, d] views (any row stride, e.g. a column of an [N, T, d] slab)."""
+                 scratch_u: torch.Tensor | None = None, scratch_i: torch.Tensor | None = None,
+                 mask_u: torch.Tensor | None = None, mask_i: torch.Tensor | None = None):
+    """One interval of the GNN loop (reference model.py:118-129): sagnn_gnn_interval_[ex_]f32.
+    user_out / item_out are [rows, d] views (any row stride, e.g. a column of an [N, T, d] slab).
+    mask_u [L, U, d/4] / mask_i [L, I, d/4] uint8 (both or neither) record the activation masks
+    the backward pass needs."""
     d = int(u0.shape[1])
     U, I = plan_user.n_rows, plan_item.n_rows
     ld_u0 = _f32_rows("u0", u0, d, U)
@@ -157,13 +165,52 @@ def gnn_interval(plan_user: SpmmPlan, plan_item: SpmmPlan, u0: torch.Tensor, i0:
         for name, s, rows in (("scratch_u", scratch_u, U), ("scratch_i", scratch_i, I)):
             if s.dtype != torch.float32 or not s.is_contiguous() or s.numel() < 2 * rows * d:
                 raise ValueError(f"{name}: need a contiguous float32 buffer of 2*{rows}*{d} elements")
-    wu, wi = plan_user.workspace(d), plan_item.workspace(d)
-    ws = wu if (wi is None or (wu is not None and wu.numel() >= wi.numel())) else wi
-    check(plan_user._lib.sagnn_gnn_interval_f32(
+    for name, m, rows in (("mask_u", mask_u, U), ("mask_i", mask_i, I)):
+        if m is not None and (m.dtype != torch.uint8 or not m.is_contiguous() or
+                              m.numel() != n_layers * rows * (d // 4)):
+            raise ValueError(f"{name}: need a contiguous uint8 tensor [{n_layers}, {rows}, {d // 4}]")
+    ws = _interval_ws(plan_user, plan_item, d)
+    check(plan_user._lib.sagnn_gnn_interval_ex_f32(
         plan_user.handle, plan_item.handle, _ptr(u0), ld_u0, _ptr(i0), ld_i0, d, int(n_layers),
         float(leaky), _ptr(scratch_u), _ptr(scratch_i), _ptr(user_out), ld_uo, _ptr(item_out), ld_io,
-        _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream()))
+        _ptr(mask_u), _ptr(mask_i), _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream()))
     return user_out, item_out
+
+
+def gnn_interval_bwd(plan_user: SpmmPlan, plan_item: SpmmPlan, grad_user_out: torch.Tensor,
+                     grad_item_out: torch.Tensor, n_layers: int, leaky: float, mask_u: torch.Tensor,
+                     mask_i: torch.Tensor, grad_u0: torch.Tensor | None = None,
+                     grad_i0: torch.Tensor | None = None, scratch_u: torch.Tensor | None = None,
+                     scratch_i: torch.Tensor | None = None):
+    """Backward of gnn_interval (sagnn_gnn_interval_bwd_f32): dL/d(user_out), dL/d(item_out) and the
+    recorded masks -> dL/d u0 [U, d], dL/d i0 [I, d]."""
+    d = int(grad_user_out.shape[1])
+    U, I = plan_user.n_rows, plan_item.n_rows
+    ld_gu = _f32_rows("grad_user_out", grad_user_out, d, U)
+    ld_gi = _f32_rows("grad_item_out", grad_item_out, d, I)
+    dev = grad_user_out.device
+    if grad_u0 is None:
+        grad_u0 = torch.empty((U, d), dtype=torch.float32, device=dev)
+    if grad_i0 is None:
+        grad_i0 = torch.empty((I, d), dtype=torch.float32, device=dev)
+    ld_du = _f32_rows("grad_u0", grad_u0, d, U)
+    ld_di = _f32_rows("grad_i0", grad_i0, d, I)
+    if scratch_u is None:
+        scratch_u = torch.empty((4, U, d), dtype=torch.float32, device=dev)
+    if scratch_i is None:
+        scratch_i = torch.empty((4, I, d), dtype=torch.float32, device=dev)
+    for name, s_, rows in (("scratch_u", scratch_u, U), ("scratch_i", scratch_i, I)):
+        if s_.dtype != torch.float32 or not s_.is_contiguous() or s_.numel() < 4 * rows * d:
+            raise ValueError(f"{name}: need a contiguous float32 buffer of 4*{rows}*{d} elements")
+    for name, m, rows in (("mask_u", mask_u, U), ("mask_i", mask_i, I)):
+        if m.dtype != torch.uint8 or not m.is_contiguous() or m.numel() != n_layers * rows * (d // 4):
+            raise ValueError(f"{name}: need a contiguous uint8 tensor [{n_layers}, {rows}, {d // 4}]")
+    ws = _interval_ws(plan_user, plan_item, d)
+    check(plan_user._lib.sagnn_gnn_interval_bwd_f32(
+        plan_user.handle, plan_item.handle, _ptr(grad_user_out), ld_gu, _ptr(grad_item_out), ld_gi, d,
+        int(n_layers), float(leaky), _ptr(mask_u), _ptr(mask_i), _ptr(scratch_u), _ptr(scratch_i),
+        _ptr(grad_u0), ld_du, _ptr(grad_i0), ld_di, _ptr(ws), 0 if ws is None else ws.numel() * 4, _stream()))
+    return grad_u0, grad_i0
 
 
 def _ntd(name: str, x: torch.Tensor, dense_td: bool = False):
