@@ -249,6 +249,22 @@ int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_
                               void* workspace, size_t workspace_bytes, void* stream);
 size_t sagnn_interval_fusion_workspace_bytes(int64_t n, int t, int d);
 
+/* ------------------------------------------------------------------------------------
+ * Dense products on the matrix cores (exact fp32), n rows huge, W small:
+ *   sagnn_dense_nn_f32:  Y[n, dout] (+)= X[n, din] @ W[din, dout] + bias      (bias nullable;
+ *       accumulate != 0 adds into Y). Replaces `inp @ W` of NNLayers.FC (Utils/NNLayers.py:108)
+ *       and tf.layers.dense (Utils/attention.py:66-72) outside the fused kernels, and the
+ *       input-gradient products of the backward pass.
+ *   sagnn_dense_tn_f32:  dW[din, dout] += X[n, din]^T @ G[n, dout];  db[dout] += column sums of G
+ *       (db nullable). The weight-gradient products; accumulates with float atomics, so zero
+ *       dW/db first and expect run-to-run differences in the last bits.
+ * din, dout: multiples of 32, dout <= 256 (tn: din <= 256 too); din*dout*4 bytes must fit LDS.
+ * -------------------------------------------------------------------------------- */
+int sagnn_dense_nn_f32(const float* X, int64_t ldx, int64_t n, int din, int dout, const float* W,
+                       const float* bias, float* Y, int64_t ldy, int accumulate, void* stream);
+int sagnn_dense_tn_f32(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din,
+                       int dout, float* dW, float* db, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -281,3 +281,50 @@ def torch_gnn_interval(u0, i0, adj_idx, tp_idx, n_layers: int, leaky: float):
         embs0.append(a0 + embs0[-1])
         embs1.append(a1 + embs1[-1])
     return sum(embs0[1:], embs0[0]), sum(embs1[1:], embs1[0])
+
+
+def torch_basic_lstm(x, kernel, bias, forget_bias: float = 1.0):
+    """basic_lstm above, in differentiable torch."""
+    import torch
+    n, t, d = x.shape
+    h = torch.zeros((n, d), dtype=x.dtype)
+    c = torch.zeros((n, d), dtype=x.dtype)
+    outs = []
+    for ts in range(t):
+        g = torch.cat([x[:, ts, :], h], dim=1) @ kernel + bias
+        gi, gj, gf, go = torch.split(g, d, dim=1)
+        c = c * torch.sigmoid(gf + forget_bias) + torch.sigmoid(gi) * torch.tanh(gj)
+        h = torch.tanh(c) * torch.sigmoid(go)
+        outs.append(h)
+    return torch.stack(outs, dim=1)
+
+
+def torch_layer_norm_td(x, gamma, beta, eps: float = 1e-12):
+    """layer_norm_td above, in differentiable torch (tf.nn.moments stops the gradient through the
+    mean inside the variance; the total derivative is the same)."""
+    import torch
+    mean = x.mean(dim=(1, 2), keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=(1, 2), keepdim=True)
+    inv = torch.rsqrt(var + eps) * gamma
+    return x * inv + (beta - mean * inv)
+
+
+def torch_mhsa_mean(x, wq, bq, wk, bk, wv, bv, heads: int):
+    """mhsa above followed by reduce_mean(axis=1), in differentiable torch."""
+    import torch
+    n, t, d = x.shape
+    dk = d // heads
+    q = (x @ wq + bq).reshape(n, t, heads, dk).permute(0, 2, 1, 3)
+    k = (x @ wk + bk).reshape(n, t, heads, dk).permute(0, 2, 1, 3)
+    v = (x @ wv + bv).reshape(n, t, heads, dk).permute(0, 2, 1, 3)
+    scores = torch.exp((q @ k.transpose(-1, -2)) / float(np.sqrt(dk)))
+    attn = scores / (scores.sum(dim=-1, keepdim=True) + 1e-8)
+    ctx = (attn @ v).permute(0, 2, 1, 3).reshape(n, t, d)
+    return ctx.mean(dim=1)
+
+
+def torch_interval_fusion(x, p: dict, heads: int):
+    """interval_fusion above in differentiable torch; p holds torch tensors."""
+    h = torch_basic_lstm(x, p["lstm_W"], p["lstm_b"], 1.0)
+    y = torch_layer_norm_td(h, p["ln_gamma"], p["ln_beta"], 1e-12)
+    return torch_mhsa_mean(y, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], heads)

@@ -1,0 +1,301 @@
+// Tall-skinny dense products on the matrix cores (gfx950, exact-fp32 v_mfma_f32_32x32x2_f32):
+// the building blocks of the backward pass of the interval fusion and of NNLayers.FC
+// (reference Utils/NNLayers.py:98-115: `inp @ W`; tf.layers.dense in Utils/attention.py:66-72;
+// their gradients as tf.gradients builds them for model.py:250).
+//
+//   nn:  Y[n, DOUT]   = X[n, DIN] @ W[DIN, DOUT] (+ bias)        n huge, W small (LDS-resident)
+//   tn:  dW[DIN,DOUT] += X[n, DIN]^T @ G[n, DOUT], db += colsum(G)   reduction over the n rows
+//
+// DIN, DOUT are multiples of 32; W (DIN*DOUT*4 bytes) must fit LDS next to the staging tiles.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kBlock = 256;
+constexpr int kRowsPerWave = 32;
+
+__device__ __forceinline__ int crow(int r, int rh) { return (r & 3) + 8 * (r >> 2) + 4 * rh; }
+
+// ---------------------------------------------------------------------------------------------
+// nn: one wavefront = 32 rows x all DOUT columns (CT tiles); W in LDS as per-(k-step, tile)
+// fragments Wf[(kk*CT + ct)*64 + l] = W[2kk + (l>>5)][ct*32 + (l&31)]; X staged 32 columns at a
+// time through a per-wave XOR-swizzled [32][32] LDS tile (next chunk prefetched in registers).
+// ---------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(kBlock, 1) void dense_nn_kernel(const float* __restrict__ X, int64_t ldx,
+                                                             int64_t n, int din,
+                                                             const float* __restrict__ W,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ Y, int64_t ldy,
+                                                             int accumulate, int64_t n_tiles) {
+  constexpr int DOUT = CT * 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Wf = lds;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  float* stage = lds + (size_t)din * DOUT + wave * (32 * 32);
+  const int ai = lane & 31, kh = lane >> 5;
+  const int cj = lane & 31, rh = lane >> 5;
+  const int fr = lane >> 3, fc4 = (lane & 7) * 4;  // fill: 8 lanes x float4 per row, 8 rows per instr
+
+  const int ksteps = din / 2;
+  for (int idx = threadIdx.x; idx < din * DOUT; idx += blockDim.x) {
+    const int l = idx & 63;
+    const int rest = idx >> 6;
+    const int ct = rest % CT;
+    const int kk = rest / CT;
+    Wf[idx] = W[(size_t)(2 * kk + (l >> 5)) * DOUT + ct * 32 + (l & 31)];
+  }
+  __syncthreads();
+  float bcol[CT];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct) bcol[ct] = bias ? bias[ct * 32 + cj] : 0.f;
+  const int nchunks = din / 32;
+
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * 128 + (int64_t)wave * kRowsPerWave;
+    if (row0 >= n) continue;  // wave-uniform
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
+    float4 xr[4];
+    auto fetch = [&](int kc) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t row = row0 + q * 8 + fr;
+        xr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < n) xr[q] = *reinterpret_cast<const float4*>(X + row * ldx + kc * 32 + fc4);
+      }
+    };
+    fetch(0);
+    for (int kc = 0; kc < nchunks; ++kc) {
+      int ai_ = ai, kh_ = kh, fr_ = fr, fc4_ = fc4;
+      asm volatile("" : "+v"(ai_), "+v"(kh_), "+v"(fr_), "+v"(fc4_));
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = q * 8 + fr_;
+        float* dst = stage + r * 32;
+        dst[(fc4_ + 0) ^ r] = xr[q].x;
+        dst[(fc4_ + 1) ^ r] = xr[q].y;
+        dst[(fc4_ + 2) ^ r] = xr[q].z;
+        dst[(fc4_ + 3) ^ r] = xr[q].w;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      float a[16];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) a[kk] = stage[ai_ * 32 + ((2 * kk + kh_) ^ ai_)];
+      __builtin_amdgcn_wave_barrier();
+      if (kc + 1 < nchunks) fetch(kc + 1);
+      const float* wf = Wf + (size_t)(kc * 16) * CT * 64 + lane;
+      float bcur[CT], bnxt[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) bcur[ct] = wf[ct * 64];
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        if (kk + 1 < 16) {
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) bnxt[ct] = wf[((kk + 1) * CT + ct) * 64];
+        }
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], bcur[ct], acc[ct], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) bcur[ct] = bnxt[ct];
+      }
+    }
+    (void)ksteps;
+    int cj_ = cj, rh_ = rh;
+    asm volatile("" : "+v"(cj_), "+v"(rh_));
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = row0 + crow(r, rh_);
+        if (row < n) {
+          float* y = Y + row * ldy + ct * 32 + cj_;
+          const float v = acc[ct][r] + bcol[ct];
+          *y = accumulate ? (*y + v) : v;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tn: the block walks 32-row chunks; X and G chunks sit row-major in LDS; the (DIN/32)x(DOUT/32)
+// output tiles are dealt to the 4 waves (TPW each), accumulated over every chunk of the block and
+// flushed once with float atomics (<= a few MB per launch). Column sums of G (bias gradient)
+// ride along, one column per thread.
+// ---------------------------------------------------------------------------------------------
+template <int TPW>
+__global__ __launch_bounds__(kBlock, 1) void dense_tn_kernel(const float* __restrict__ X, int64_t ldx,
+                                                             const float* __restrict__ G, int64_t ldg,
+                                                             int64_t n, int din, int dout,
+                                                             float* __restrict__ dW,
+                                                             float* __restrict__ db, int64_t n_chunks) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;                    // [32][din]
+  float* gs = lds + 32 * din;         // [32][dout]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+  const int nb = dout / 32;
+  const int n_out_tiles = (din / 32) * nb;
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float colsum = 0.f;
+
+  for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    const int64_t row0 = ch * 32;
+    __syncthreads();  // previous chunk fully consumed
+    for (int i = threadIdx.x * 4; i < 32 * din; i += blockDim.x * 4) {
+      const int r = i / din, c = i - r * din;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < n) v = *reinterpret_cast<const float4*>(X + (row0 + r) * ldx + c);
+      *reinterpret_cast<float4*>(xs + i) = v;
+    }
+    for (int i = threadIdx.x * 4; i < 32 * dout; i += blockDim.x * 4) {
+      const int r = i / dout, c = i - r * dout;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < n) v = *reinterpret_cast<const float4*>(G + (row0 + r) * ldg + c);
+      *reinterpret_cast<float4*>(gs + i) = v;
+    }
+    __syncthreads();
+    if (db && (int)threadIdx.x < dout) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) s += gs[r * dout + threadIdx.x];
+      colsum += s;
+    }
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int row = 2 * kk + kh;
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int tt = wave * TPW + j;
+        if (tt < n_out_tiles) {  // wave-uniform
+          const int ta = tt / nb, tb = tt - ta * nb;
+          const float av = xs[row * din + ta * 32 + li];   // A[i = din index][k = row]
+          const float bv = gs[row * dout + tb * 32 + li];  // B[k = row][j = dout index]
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int tt = wave * TPW + j;
+    if (tt < n_out_tiles) {
+      const int ta = tt / nb, tb = tt - ta * nb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        atomicAdd(dW + (size_t)(ta * 32 + crow(r, kh)) * dout + tb * 32 + li, acc[j][r]);
+    }
+  }
+  if (db && (int)threadIdx.x < dout) atomicAdd(db + threadIdx.x, colsum);
+}
+
+int cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+  }
+  return cus;
+}
+
+template <int CT>
+int launch_nn(const float* X, int64_t ldx, int64_t n, int din, const float* W, const float* bias, float* Y,
+              int64_t ldy, int accumulate, hipStream_t s) {
+  const size_t lds = ((size_t)din * CT * 32 + 4 * 32 * 32) * sizeof(float);
+  if (lds > 160 * 1024) return sagnn::fail(SAGNN_ERR_DIM, "dense_nn: W %d x %d does not fit LDS", din, CT * 32);
+  static size_t configured = 0;
+  if (lds > configured) {
+    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_nn_kernel<CT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = lds;
+  }
+  const int64_t n_tiles = (n + 127) / 128;
+  const int64_t blocks = n_tiles < cu_count() ? n_tiles : cu_count();
+  hipLaunchKernelGGL(dense_nn_kernel<CT>, dim3((unsigned)blocks), dim3(kBlock), lds, s, X, ldx, n, din, W, bias, Y,
+                     ldy, accumulate, n_tiles);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+template <int TPW>
+int launch_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW,
+              float* db, hipStream_t s) {
+  const size_t lds = (size_t)32 * (din + dout) * sizeof(float);
+  static size_t configured = 0;
+  if (lds > configured) {
+    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_tn_kernel<TPW>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = lds;
+  }
+  const int64_t n_chunks = (n + 31) / 32;
+  const int64_t blocks = n_chunks < cu_count() ? n_chunks : cu_count();
+  hipLaunchKernelGGL(dense_tn_kernel<TPW>, dim3((unsigned)blocks), dim3(kBlock), lds, s, X, ldx, G, ldg, n, din,
+                     dout, dW, db, n_chunks);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+int check_xy(const char* name, const void* p, int64_t ld, int cols) {
+  if (!p) return sagnn::fail(SAGNN_ERR_NULL, "%s is NULL", name);
+  if (!sagnn::aligned16(p) || (ld & 3)) return sagnn::fail(SAGNN_ERR_ALIGN, "%s: need 16-byte aligned rows", name);
+  if (ld < cols) return sagnn::fail(SAGNN_ERR_ARG, "%s: ld %lld < %d columns", name, (long long)ld, cols);
+  return SAGNN_OK;
+}
+
+}  // namespace
+
+extern "C" int sagnn_dense_nn_f32(const float* X, int64_t ldx, int64_t n, int din, int dout, const float* W,
+                                  const float* bias, float* Y, int64_t ldy, int accumulate, void* stream) {
+  if (n < 0 || din < 32 || dout < 32 || (din & 31) || (dout & 31) || dout > 256)
+    return sagnn::fail(SAGNN_ERR_DIM, "dense_nn: need din, dout multiples of 32, dout <= 256 (got %d, %d)", din, dout);
+  if (int rc = check_xy("X", X, ldx, din)) return rc;
+  if (int rc = check_xy("Y", Y, ldy, dout)) return rc;
+  if (!W) return sagnn::fail(SAGNN_ERR_NULL, "W is NULL");
+  if (n == 0) return SAGNN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  switch (dout / 32) {
+    case 1: return launch_nn<1>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
+    case 2: return launch_nn<2>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
+    case 3: return launch_nn<3>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
+    case 4: return launch_nn<4>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
+    case 5: return launch_nn<5>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
+    case 6: return launch_nn<6>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
+    case 7: return launch_nn<7>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
+    default: return launch_nn<8>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
+  }
+}
+
+extern "C" int sagnn_dense_tn_f32(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din,
+                                  int dout, float* dW, float* db, void* stream) {
+  if (n < 0 || din < 32 || dout < 32 || (din & 31) || (dout & 31) || dout > 256 || din > 256)
+    return sagnn::fail(SAGNN_ERR_DIM, "dense_tn: need din, dout multiples of 32 and <= 256 (got %d, %d)", din, dout);
+  if (int rc = check_xy("X", X, ldx, din)) return rc;
+  if (int rc = check_xy("G", G, ldg, dout)) return rc;
+  if (!dW) return sagnn::fail(SAGNN_ERR_NULL, "dW is NULL");
+  if (n == 0) return SAGNN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int tiles = (din / 32) * (dout / 32);
+  const int tpw = (tiles + 3) / 4;
+  if (tpw <= 1) return launch_tn<1>(X, ldx, G, ldg, n, din, dout, dW, db, s);
+  if (tpw <= 2) return launch_tn<2>(X, ldx, G, ldg, n, din, dout, dW, db, s);
+  if (tpw <= 3) return launch_tn<3>(X, ldx, G, ldg, n, din, dout, dW, db, s);
+  if (tpw <= 4) return launch_tn<4>(X, ldx, G, ldg, n, din, dout, dW, db, s);
+  if (tpw <= 8) return launch_tn<8>(X, ldx, G, ldg, n, din, dout, dW, db, s);
+  return launch_tn<16>(X, ldx, G, ldg, n, din, dout, dW, db, s);
+}

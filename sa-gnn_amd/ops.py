@@ -296,3 +296,31 @@ def interval_fusion(x: torch.Tensor, p: dict, heads: int, out: torch.Tensor | No
         _vec("bv", p["bv"], d), out.data_ptr(), ldo, workspace.data_ptr(),
         workspace.numel() * workspace.element_size(), _stream()))
     return out
+
+
+def dense_nn(x: torch.Tensor, W: torch.Tensor, bias: torch.Tensor | None = None, out: torch.Tensor | None = None,
+             accumulate: bool = False):
+    """Y (+)= X @ W + bias on the matrix cores (sagnn_dense_nn_f32). x [n, din] (row stride free),
+    W [din, dout] contiguous."""
+    n, din = int(x.shape[0]), int(x.shape[1])
+    dout = int(W.shape[1])
+    ldx = _f32_rows("x", x, din)
+    if out is None:
+        out = torch.empty((n, dout), dtype=torch.float32, device=x.device)
+    ldy = _f32_rows("out", out, dout, n)
+    check(_lib.load().sagnn_dense_nn_f32(x.data_ptr(), ldx, n, din, dout, _vec("W", W, din * dout),
+                                         None if bias is None else _vec("bias", bias, dout), out.data_ptr(), ldy,
+                                         int(accumulate), _stream()))
+    return out
+
+
+def dense_tn(x: torch.Tensor, g: torch.Tensor, dW: torch.Tensor, db: torch.Tensor | None = None):
+    """dW += X^T @ G, db += colsum(G) (sagnn_dense_tn_f32). Accumulates: zero dW/db first."""
+    n, din = int(x.shape[0]), int(x.shape[1])
+    dout = int(g.shape[1])
+    ldx = _f32_rows("x", x, din)
+    ldg = _f32_rows("g", g, dout, n)
+    check(_lib.load().sagnn_dense_tn_f32(x.data_ptr(), ldx, g.data_ptr(), ldg, n, din, dout,
+                                         _vec("dW", dW, din * dout), None if db is None else _vec("db", db, dout),
+                                         _stream()))
+    return dW

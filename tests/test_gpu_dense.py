@@ -1,0 +1,42 @@
+"""GPU parity of the dense MFMA building blocks against float64 matmul."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,din,dout", [(1000, 64, 192), (129, 192, 64), (5000, 256, 128), (31, 32, 96), (300, 96, 32), (4097, 128, 256)])
+def test_dense_nn(dev, n, din, dout):
+    from sa_gnn_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(n + din)
+    x = torch.randn((n, din), generator=g)
+    W = torch.randn((din, dout), generator=g) / din ** 0.5
+    b = torch.randn(dout, generator=g)
+    want = x.double() @ W.double() + b.double()
+    got = ops.dense_nn(x.to(dev), W.to(dev), b.to(dev))
+    torch.testing.assert_close(got.cpu().double(), want, rtol=1e-4, atol=1e-5)
+    # strided input/output views and accumulate
+    big = torch.zeros((n, din + 64))
+    big[:, 32:32 + din] = x
+    out = torch.ones((n, dout + 32), device=dev)
+    ops.dense_nn(big.to(dev)[:, 32:32 + din], W.to(dev), None, out=out[:, :dout], accumulate=True)
+    torch.testing.assert_close(out[:, :dout].cpu().double(), x.double() @ W.double() + 1.0, rtol=1e-4, atol=1e-5)
+    assert torch.all(out[:, dout:] == 1)
+
+
+@pytest.mark.parametrize("n,din,dout", [(1000, 64, 192), (77, 128, 256), (20000, 128, 256), (513, 32, 96), (64, 192, 64), (999, 256, 128)])
+def test_dense_tn(dev, n, din, dout):
+    from sa_gnn_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(n + dout)
+    x = torch.randn((n, din), generator=gen)
+    g = torch.randn((n, dout), generator=gen)
+    dW = torch.zeros((din, dout), device=dev)
+    db = torch.zeros(dout, device=dev)
+    ops.dense_tn(x.to(dev), g.to(dev), dW, db)
+    want = x.double().T @ g.double()
+    scale = float(want.abs().max())
+    torch.testing.assert_close(dW.cpu().double(), want, rtol=1e-4, atol=2e-6 * scale + 1e-5)
+    torch.testing.assert_close(db.cpu().double(), g.double().sum(0), rtol=1e-4, atol=1e-4)
+    ops.dense_tn(x.to(dev), g.to(dev), dW, None)                    # accumulates
+    torch.testing.assert_close(dW.cpu().double(), 2 * want, rtol=1e-4, atol=4e-6 * scale + 1e-5)
