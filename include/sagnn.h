@@ -250,6 +250,46 @@ int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_
 size_t sagnn_interval_fusion_workspace_bytes(int64_t n, int t, int d);
 
 /* ------------------------------------------------------------------------------------
+ * Backward of the interval fusion: the gradients tf.gradients derives for
+ * model.py:135-155. The host (sa-gnn_amd/autograd.py) sequences these entries with the dense
+ * products below; d in {32, 64}, d_k a power of two.
+ *
+ * sagnn_lstm_fwd_train_f32 — sagnn_lstm_fwd_f32 that also stores the gate activations
+ *   gates [n, t, 4d] = sigmoid(i) | tanh(j) | sigmoid(f + forget_bias) | sigmoid(o) and the cell
+ *   state cell [n, t, d].
+ * sagnn_attn_bwd_f32 — qkv [n, t, 3d] (Q | K | V rows, as x@W+b produced them) is overwritten
+ *   with dQ | dK | dV given g_out = dL/d(mean-over-queries context) [n, d].
+ * sagnn_layernorm_td_bwd_f32 — dy -> dh (may alias dy), dgamma/dbeta accumulated with atomics
+ *   (zero them first).
+ * sagnn_lstm_bwd_step_f32 — step ts of BPTT: dh_ext [n, t, d] (gradient arriving at the emitted
+ *   h, scaled by drop_scale if given), dh_rec [n, d] (recurrent gradient, NULL at the last step),
+ *   dc_in [n, d] (NULL at the last step) -> dgates [n, 4d] (pre-activation gradients, i|j|f|o)
+ *   and dc_out [n, d].
+ * -------------------------------------------------------------------------------- */
+int sagnn_lstm_fwd_train_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
+                             const float* W, const float* b, float forget_bias, const float* drop_scale,
+                             float* h, int64_t ld_h, float* gates, float* cell, void* stream);
+int sagnn_attn_bwd_f32(float* qkv, const float* g_out, int64_t ld_g, int64_t n, int t, int d, int heads,
+                       void* stream);
+int sagnn_layernorm_td_bwd_f32(const float* h, int64_t ld_h, const float* dy, int64_t ld_dy, int64_t n, int t,
+                               int d, const float* gamma, float eps, float* dh, int64_t ld_dh, float* dgamma,
+                               float* dbeta, void* stream);
+int sagnn_lstm_bwd_step_f32(const float* gates, const float* cell, const float* dh_ext, int64_t ld_dhe,
+                            const float* drop_scale, const float* dh_rec, int64_t ld_dhr, const float* dc_in,
+                            float* dgates, float* dc_out, int64_t n, int t, int d, int ts, void* stream);
+
+/* out[i] = a[i] * b[i] (dropout scaling of the emitted LSTM output, model.py:139). */
+int sagnn_mul_f32(const float* a, const float* b, float* out, int64_t count, void* stream);
+
+/* One tf.train.AdamOptimizer step (model.py:248-250) with the L2 term of regLoss
+ * (args.reg * Regularize(), model.py:245, Utils/NNLayers.py:159-175) folded into the gradient:
+ *   g' = g + 2*l2*p;  m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2
+ *   p -= lr*sqrt(1 - b2^step)/(1 - b1^step) * m / (sqrt(v) + eps)        (step counts from 1)
+ * The caller applies the staircase decay lr = lr0 * decay^floor(step/decay_step) (model.py:249). */
+int sagnn_adam_step_f32(float* param, const float* grad, float* m, float* v, int64_t count, float lr,
+                        float beta1, float beta2, float eps, float l2, int64_t step, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Dense products on the matrix cores (exact fp32), n rows huge, W small:
  *   sagnn_dense_nn_f32:  Y[n, dout] (+)= X[n, din] @ W[din, dout] + bias      (bias nullable;
  *       accumulate != 0 adds into Y). Replaces `inp @ W` of NNLayers.FC (Utils/NNLayers.py:108)

@@ -63,6 +63,16 @@ SIGNATURES = {
     "sagnn_gnn_interval_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                        c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "sagnn_lstm_fwd_train_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_float,
+                                         c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "sagnn_attn_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
+    "sagnn_layernorm_td_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p,
+                                           c_float, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "sagnn_lstm_bwd_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                        c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "sagnn_mul_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sagnn_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
+                                    c_float, c_float, c_int64, c_void_p]),
     "sagnn_dense_nn_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                    c_int, c_void_p]),
     "sagnn_dense_tn_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,

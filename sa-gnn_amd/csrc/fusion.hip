@@ -241,8 +241,8 @@ extern "C" int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t ld_t, in
   // VALU formulation (A/B runs)
   const bool vec_ok = sagnn::aligned16(x) && (ld_n & 3) == 0 && (ld_t & 3) == 0;
   if (sagnn::lstm_mfma_supported(d) && vec_ok && !sagnn::force_valu())
-    return sagnn::lstm_fwd_mfma(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h,
-                                static_cast<hipStream_t>(stream));
+    return sagnn::lstm_fwd_mfma(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, nullptr,
+                                nullptr, static_cast<hipStream_t>(stream));
   return sagnn::lstm_fwd_valu(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h,
                               static_cast<hipStream_t>(stream));
 }
@@ -314,4 +314,20 @@ extern "C" int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t l
                                     Wv, bv, out, ld_out, static_cast<hipStream_t>(stream));
   if (int rc = sagnn_layernorm_td_f32(h, ldw, d, n, t, d, ln_gamma, ln_beta, ln_eps, h, ldw, stream)) return rc;
   return sagnn_mhsa_mean_f32(h, ldw, d, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out, stream);
+}
+
+
+extern "C" int sagnn_lstm_fwd_train_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
+                                        const float* W, const float* b, float forget_bias,
+                                        const float* drop_scale, float* h, int64_t ld_h, float* gates,
+                                        float* cell, void* stream) {
+  if (int rc = check_dims(n, t, d)) return rc;
+  if (!x || !W || !b || !h || !gates || !cell) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (int rc = check_strides(ld_n, ld_t, n, t, d)) return rc;
+  if (ld_h < (int64_t)t * d) return sagnn::fail(SAGNN_ERR_ARG, "ld_h smaller than t*d");
+  if (!sagnn::lstm_mfma_supported(d)) return sagnn::fail(SAGNN_ERR_DIM, "training path supports d = 32 or 64, got %d", d);
+  if (!sagnn::aligned16(x) || (ld_n & 3) || (ld_t & 3)) return sagnn::fail(SAGNN_ERR_ALIGN, "x rows must be 16-byte aligned");
+  if (n == 0) return SAGNN_OK;
+  return sagnn::lstm_fwd_mfma(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, gates, cell,
+                              static_cast<hipStream_t>(stream));
 }

@@ -1,0 +1,350 @@
+// Backward pieces of the interval fusion (reference: what tf.gradients derives for
+// model.py:135-155 when model.py:250 minimises the loss). The GEMM-shaped parts go through
+// dense.hip; this file holds the per-node / element-wise parts:
+//   attn_bwd:      Q|K|V and dL/d(mean context) -> dQ|dK|dV              (Utils/attention.py:35-45)
+//   layernorm_bwd: dL/dy -> dL/dh, dgamma, dbeta                        (model.py:152-153)
+//   lstm_bwd_step: one step of BPTT on saved gate activations            (model.py:135-146)
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// One node per group of d threads (thread = feature column j, head h = j / dk). qkv [n, t, 3d]
+// (Q | K | V per row) is overwritten in place with dQ | dK | dV.
+// out = mean_q sum_s a_qs V[s], a_qs = e_qs / (R_q + 1e-8), e = exp(Q K^T * scale). With
+// g = dL/dout / t (the same for every query position):
+//   p_s   = sum_{j in head} g_j V[s][j]
+//   dz_qs = a_qs (p_s - sum_s' a_qs' p_s')
+//   dQ[q] = scale * sum_s dz_qs K[s];  dK[s] = scale * sum_q dz_qs Q[q];  dV[s] = g * sum_q a_qs
+__global__ void attn_bwd_kernel(float* __restrict__ qkv, const float* __restrict__ g_out, int64_t ld_g,
+                                int64_t n, int t, int d, int heads) {
+  extern __shared__ float sm[];
+  const int j = threadIdx.x % d;
+  const int slot = threadIdx.x / d;
+  const int slots = blockDim.x / d;
+  const int dk = d / heads;
+  const int h = j / dk, c = j % dk, h0 = h * dk;
+  const int td = t * d, tt = t * t;
+  float* qs = sm + (size_t)slot * (3 * td + heads * (tt + 2 * t));
+  float* ks = qs + td;
+  float* vs = ks + td;
+  float* as = vs + td;            // [heads][t][t]: e, then a
+  float* ps = as + heads * tt;    // [heads][t]: p_s
+  float* ds = ps + heads * t;     // [heads][t]: sum_s' a_qs' p_s' per query
+  const float scale = 1.f / sqrtf((float)dk);
+  const float inv_t = 1.f / (float)t;
+
+  for (int64_t node0 = (int64_t)blockIdx.x * slots; node0 < n; node0 += (int64_t)gridDim.x * slots) {
+    const int64_t node = node0 + slot;
+    const bool valid = node < n;
+    float* row = qkv + (valid ? node : 0) * (int64_t)(3 * td);
+    for (int ts = 0; ts < t; ++ts) {
+      qs[ts * d + j] = valid ? row[ts * 3 * d + j] : 0.f;
+      ks[ts * d + j] = valid ? row[ts * 3 * d + d + j] : 0.f;
+      vs[ts * d + j] = valid ? row[ts * 3 * d + 2 * d + j] : 0.f;
+    }
+    const float g = valid ? g_out[node * ld_g + j] * inv_t : 0.f;
+    __syncthreads();
+    // e_qs of this head: its dk lanes split the (q, s) pairs
+    for (int pr = c; pr < tt; pr += dk) {
+      const int q = pr / t, s = pr - q * t;
+      float z = 0.f;
+      for (int cc = 0; cc < dk; ++cc) z = fmaf(qs[q * d + h0 + cc], ks[s * d + h0 + cc], z);
+      as[h * tt + pr] = expf(z * scale);
+    }
+    // p_s: head sum of g_j V[s][j] (the dk lanes of a head are adjacent lanes of one wave)
+    for (int s = 0; s < t; ++s) {
+      float part = g * vs[s * d + j];
+      for (int off = 1; off < dk; off <<= 1) part += __shfl_xor(part, off);
+      if (c == 0) ps[h * t + s] = part;
+    }
+    __syncthreads();
+    // normalise the rows: lane c takes queries q = c, c + dk, ...
+    for (int q = c; q < t; q += dk) {
+      float* ar = as + h * tt + q * t;
+      float rsum = 0.f;
+      for (int s = 0; s < t; ++s) rsum += ar[s];
+      const float inv = 1.f / (rsum + 1e-8f);
+      float dot = 0.f;
+      for (int s = 0; s < t; ++s) {
+        const float a = ar[s] * inv;
+        ar[s] = a;
+        dot = fmaf(a, ps[h * t + s], dot);
+      }
+      ds[h * t + q] = dot;
+    }
+    __syncthreads();
+    // per-column outputs, in place
+    if (valid) {
+      for (int q = 0; q < t; ++q) {
+        const float* ar = as + h * tt + q * t;
+        const float dot = ds[h * t + q];
+        float dq = 0.f;
+        for (int s = 0; s < t; ++s) dq = fmaf(ar[s] * (ps[h * t + s] - dot), ks[s * d + j], dq);
+        row[q * 3 * d + j] = dq * scale;
+      }
+      for (int s = 0; s < t; ++s) {
+        const float p = ps[h * t + s];
+        float dkv = 0.f, asum = 0.f;
+        for (int q = 0; q < t; ++q) {
+          const float a = as[h * tt + q * t + s];
+          dkv = fmaf(a * (p - ds[h * t + q]), qs[q * d + j], dkv);
+          asum += a;
+        }
+        row[s * 3 * d + d + j] = dkv * scale;
+        row[s * 3 * d + 2 * d + j] = g * asum;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// layer_norm over (t, d) per node, backward. y = (h - mean) * rstd * gamma + beta.
+//   dhat = dy * gamma;  dh = rstd * (dhat - mean(dhat) - hhat * mean(dhat * hhat))
+//   dgamma[k] += sum dy * hhat;  dbeta[k] += sum dy        (atomics once per thread at the end)
+// One wavefront per node, persistent grid. Needs 64 % d == 0 or d % 64 == 0 so that a lane's
+// elements fall in a fixed set of at most 4 columns.
+__global__ void layernorm_td_bwd_kernel(const float* __restrict__ h, int64_t ld_h, const float* dy,
+                                        int64_t ld_dy, int64_t n, int t, int d,
+                                        const float* __restrict__ gamma, float eps, float* dh,
+                                        int64_t ld_dh, float* __restrict__ dgamma,
+                                        float* __restrict__ dbeta) {
+  const int lane = threadIdx.x & 63;
+  const int waves = (gridDim.x * blockDim.x) >> 6;
+  const int td = t * d;
+  const float inv_m = 1.f / (float)td;
+  const int ncol = d >= 64 ? d / 64 : 1;
+  float gacc[4] = {0.f, 0.f, 0.f, 0.f}, bacc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t node = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; node < n; node += waves) {
+    const float* hr = h + node * ld_h;
+    const float* dyr = dy + node * ld_dy;
+    float s = 0.f;
+    for (int i = lane; i < td; i += 64) s += hr[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s * inv_m;
+    float v = 0.f;
+    for (int i = lane; i < td; i += 64) {
+      const float dl = hr[i] - mean;
+      v = fmaf(dl, dl, v);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const float rstd = rsqrtf(v * inv_m + eps);
+    float s1 = 0.f, s2 = 0.f;
+    int m = 0;
+    for (int i = lane; i < td; i += 64, ++m) {
+      const int k = i % d;
+      const float hhat = (hr[i] - mean) * rstd;
+      const float g = dyr[i];
+      const float dhat = g * gamma[k];
+      s1 += dhat;
+      s2 = fmaf(dhat, hhat, s2);
+      const int slot = m % ncol;
+      gacc[slot] = fmaf(g, hhat, gacc[slot]);
+      bacc[slot] += g;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s1 += __shfl_xor(s1, off);
+      s2 += __shfl_xor(s2, off);
+    }
+    s1 *= inv_m;
+    s2 *= inv_m;
+    float* dhr = dh + node * ld_dh;
+    for (int i = lane; i < td; i += 64) {
+      const int k = i % d;
+      const float hhat = (hr[i] - mean) * rstd;
+      dhr[i] = rstd * (dyr[i] * gamma[k] - s1 - hhat * s2);
+    }
+  }
+  for (int slot = 0; slot < ncol; ++slot) {
+    const int k = (lane + 64 * slot) % d;
+    atomicAdd(dgamma + k, gacc[slot]);
+    atomicAdd(dbeta + k, bacc[slot]);
+  }
+}
+
+// One BPTT step on saved activations. gates [n, t, 4d] = sigmoid(i) | tanh(j) | sigmoid(f + fb) |
+// sigmoid(o); cell [n, t, d]. h = tanh(c) * o, c = c_prev * f + i * j.
+__global__ void lstm_bwd_step_kernel(const float* __restrict__ gates, const float* __restrict__ cell,
+                                     const float* __restrict__ dh_ext, int64_t ld_dhe,
+                                     const float* __restrict__ drop, const float* __restrict__ dh_rec,
+                                     int64_t ld_dhr, const float* __restrict__ dc_in,
+                                     float* __restrict__ dgates, float* __restrict__ dc_out, int64_t n,
+                                     int t, int d, int ts) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int d4 = d >> 2;
+  if (idx >= n * d4) return;
+  const int64_t node = idx / d4;
+  const int col = (int)(idx - node * d4) * 4;
+  const int64_t gbase = (node * t + ts) * (int64_t)(4 * d) + col;
+  const float4 gi = *reinterpret_cast<const float4*>(gates + gbase);
+  const float4 gj = *reinterpret_cast<const float4*>(gates + gbase + d);
+  const float4 gf = *reinterpret_cast<const float4*>(gates + gbase + 2 * d);
+  const float4 go = *reinterpret_cast<const float4*>(gates + gbase + 3 * d);
+  const float4 c = *reinterpret_cast<const float4*>(cell + (node * t + ts) * (int64_t)d + col);
+  float4 cp = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ts > 0) cp = *reinterpret_cast<const float4*>(cell + (node * t + ts - 1) * (int64_t)d + col);
+  float4 dh = *reinterpret_cast<const float4*>(dh_ext + node * ld_dhe + (int64_t)ts * d + col);
+  if (drop) {
+    const float4 sc = *reinterpret_cast<const float4*>(drop + (node * t + ts) * (int64_t)d + col);
+    dh.x *= sc.x;
+    dh.y *= sc.y;
+    dh.z *= sc.z;
+    dh.w *= sc.w;
+  }
+  if (dh_rec) {
+    const float4 r = *reinterpret_cast<const float4*>(dh_rec + node * ld_dhr + col);
+    dh.x += r.x;
+    dh.y += r.y;
+    dh.z += r.z;
+    dh.w += r.w;
+  }
+  float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (dc_in) dc = *reinterpret_cast<const float4*>(dc_in + node * (int64_t)d + col);
+  float4 o_i, o_j, o_f, o_o, o_c;
+#define SAGNN_LSTM_BWD(e)                                 \
+  {                                                       \
+    const float tc = tanhf(c.e);                          \
+    const float dcv = dc.e + dh.e * go.e * (1.f - tc * tc); \
+    o_o.e = dh.e * tc * go.e * (1.f - go.e);              \
+    o_i.e = dcv * gj.e * gi.e * (1.f - gi.e);             \
+    o_j.e = dcv * gi.e * (1.f - gj.e * gj.e);             \
+    o_f.e = dcv * cp.e * gf.e * (1.f - gf.e);             \
+    o_c.e = dcv * gf.e;                                   \
+  }
+  SAGNN_LSTM_BWD(x)
+  SAGNN_LSTM_BWD(y)
+  SAGNN_LSTM_BWD(z)
+  SAGNN_LSTM_BWD(w)
+#undef SAGNN_LSTM_BWD
+  float* dg = dgates + node * (int64_t)(4 * d) + col;
+  *reinterpret_cast<float4*>(dg) = o_i;
+  *reinterpret_cast<float4*>(dg + d) = o_j;
+  *reinterpret_cast<float4*>(dg + 2 * d) = o_f;
+  *reinterpret_cast<float4*>(dg + 3 * d) = o_o;
+  *reinterpret_cast<float4*>(dc_out + node * (int64_t)d + col) = o_c;
+}
+
+// out[i] = a[i] * b[i]
+__global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                           int64_t count) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < count) {
+    const float4 x = *reinterpret_cast<const float4*>(a + i), y = *reinterpret_cast<const float4*>(b + i);
+    *reinterpret_cast<float4*>(out + i) = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+  } else {
+    for (int64_t k = i; k < count; ++k) out[k] = a[k] * b[k];
+  }
+}
+
+// TF1 AdamOptimizer step with the L2 term of the reference's regLoss folded into the gradient:
+//   g' = g + 2*l2*p;  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2;  p -= lr_t * m / (sqrt(v) + eps)
+// lr_t = lr * sqrt(1 - b2^step) / (1 - b1^step) is formed by the caller.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t count, float lr_t, float b1, float b2, float eps,
+                            float l2) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float pv = p[i];
+  const float gv = g[i] + 2.f * l2 * pv;
+  const float mv = b1 * m[i] + (1.f - b1) * gv;
+  const float vv = b2 * v[i] + (1.f - b2) * gv * gv;
+  m[i] = mv;
+  v[i] = vv;
+  p[i] = pv - lr_t * mv / (sqrtf(vv) + eps);
+}
+
+}  // namespace
+
+extern "C" int sagnn_mul_f32(const float* a, const float* b, float* out, int64_t count, void* stream) {
+  if (!a || !b || !out) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (count <= 0) return SAGNN_OK;
+  if (!sagnn::aligned16(a) || !sagnn::aligned16(b) || !sagnn::aligned16(out))
+    return sagnn::fail(SAGNN_ERR_ALIGN, "operands must be 16-byte aligned");
+  const int64_t blocks = ((count + 3) / 4 + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(mul_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a, b, out, count);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_adam_step_f32(float* param, const float* grad, float* m, float* v, int64_t count, float lr,
+                                   float beta1, float beta2, float eps, float l2, int64_t step, void* stream) {
+  if (!param || !grad || !m || !v) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (step < 1) return sagnn::fail(SAGNN_ERR_ARG, "step counts from 1");
+  if (count <= 0) return SAGNN_OK;
+  const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+  const int64_t blocks = (count + kBlock - 1) / kBlock;
+  if (blocks > INT32_MAX) return sagnn::fail(SAGNN_ERR_ARG, "grid too large");
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), param,
+                     grad, m, v, count, (float)lr_t, beta1, beta2, eps, l2);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_attn_bwd_f32(float* qkv, const float* g_out, int64_t ld_g, int64_t n, int t, int d,
+                                  int heads, void* stream) {
+  if (n < 0 || t < 1 || t > 64 || d < 4 || d > 256 || (d & 3)) return sagnn::fail(SAGNN_ERR_DIM, "bad n/t/d");
+  if (heads < 1 || d % heads) return sagnn::fail(SAGNN_ERR_DIM, "heads = %d does not divide d = %d", heads, d);
+  const int dk = d / heads;
+  if (dk & (dk - 1)) return sagnn::fail(SAGNN_ERR_DIM, "d_k = %d must be a power of two", dk);
+  if (64 % d != 0 && d % 64 != 0) return sagnn::fail(SAGNN_ERR_DIM, "d = %d: need 64 %% d == 0 or d %% 64 == 0", d);
+  if (!qkv || !g_out) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (n == 0) return SAGNN_OK;
+  int slots = kBlock / d > 0 ? kBlock / d : 1;
+  const size_t per_slot = (size_t)(3 * t * d + heads * (t * t + 2 * t)) * sizeof(float);
+  while (slots > 1 && slots * per_slot > 64 * 1024) slots >>= 1;
+  const size_t lds = slots * per_slot;
+  if (lds > 160 * 1024) return sagnn::fail(SAGNN_ERR_DIM, "t*d too large for LDS");
+  static size_t configured = 0;
+  if (lds > configured) {
+    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = lds;
+  }
+  int64_t blocks = (n + slots - 1) / slots;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)blocks), dim3(slots * d), lds, static_cast<hipStream_t>(stream),
+                     qkv, g_out, ld_g, n, t, d, heads);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_layernorm_td_bwd_f32(const float* h, int64_t ld_h, const float* dy, int64_t ld_dy, int64_t n,
+                                          int t, int d, const float* gamma, float eps, float* dh, int64_t ld_dh,
+                                          float* dgamma, float* dbeta, void* stream) {
+  if (n < 0 || t < 1 || t > 64 || d < 4 || d > 256 || (d & 3)) return sagnn::fail(SAGNN_ERR_DIM, "bad n/t/d");
+  if (64 % d != 0 && d % 64 != 0) return sagnn::fail(SAGNN_ERR_DIM, "d = %d: need 64 %% d == 0 or d %% 64 == 0", d);
+  if (!h || !dy || !gamma || !dh || !dgamma || !dbeta) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (ld_h < (int64_t)t * d || ld_dy < (int64_t)t * d || ld_dh < (int64_t)t * d)
+    return sagnn::fail(SAGNN_ERR_ARG, "node stride smaller than t*d");
+  if (n == 0) return SAGNN_OK;
+  int64_t blocks = (n + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(layernorm_td_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), h, ld_h, dy, ld_dy, n, t, d, gamma, eps, dh, ld_dh, dgamma,
+                     dbeta);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_lstm_bwd_step_f32(const float* gates, const float* cell, const float* dh_ext, int64_t ld_dhe,
+                                       const float* drop_scale, const float* dh_rec, int64_t ld_dhr,
+                                       const float* dc_in, float* dgates, float* dc_out, int64_t n, int t, int d,
+                                       int ts, void* stream) {
+  if (n < 0 || t < 1 || d < 4 || (d & 3) || ts < 0 || ts >= t) return sagnn::fail(SAGNN_ERR_DIM, "bad n/t/d/ts");
+  if (!gates || !cell || !dh_ext || !dgates || !dc_out) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if ((ld_dhe & 3) || (dh_rec && (ld_dhr & 3))) return sagnn::fail(SAGNN_ERR_ALIGN, "strides must be multiples of 4");
+  if (n == 0) return SAGNN_OK;
+  const int64_t total = n * (d / 4);
+  const int64_t blocks = (total + kBlock - 1) / kBlock;
+  if (blocks > INT32_MAX) return sagnn::fail(SAGNN_ERR_ARG, "grid too large");
+  hipLaunchKernelGGL(lstm_bwd_step_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     gates, cell, dh_ext, ld_dhe, drop_scale, dh_rec, ld_dhr, dc_in, dgates, dc_out, n, t, d, ts);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}

@@ -113,11 +113,14 @@ __device__ __forceinline__ void mfma_half(f32x16 (&acc)[4 * HF], const float (&a
 // ---------------------------------------------------------------------------------------------
 // LSTM: TF 1.14 BasicLSTMCell over T steps, zero initial state (reference model.py:135-146).
 // ---------------------------------------------------------------------------------------------
-template <int D>
+// SAVE: training forward — additionally stores the gate activations (i | j | f | o after their
+// non-linearities) [n, t, 4D] and the cell state [n, t, D] for the backward pass.
+template <int D, bool SAVE>
 __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
     const float* __restrict__ x, int64_t ld_n, int64_t ld_t, int64_t n, int t,
     const float* __restrict__ W, const float* __restrict__ bias, float forget_bias,
-    const float* __restrict__ drop, float* __restrict__ h_out, int64_t ld_h, int64_t n_tiles) {
+    const float* __restrict__ drop, float* __restrict__ h_out, int64_t ld_h,
+    float* __restrict__ gates_out, float* __restrict__ c_out, int64_t n_tiles) {
   constexpr int NC = 4 * D;        // gate columns
   constexpr int CT = NC / 32;      // column tiles (8 at D=64)
   constexpr int HF = CT / 4;       // b128 reads per k-step
@@ -208,13 +211,23 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
         for (int r = 0; r < 16; ++r) {
           const float gi = acc[ht][r] + bcol[ht], gj = acc[HT + ht][r] + bcol[HT + ht];
           const float gf = acc[2 * HT + ht][r] + bcol[2 * HT + ht], go = acc[3 * HT + ht][r] + bcol[3 * HT + ht];
-          const float cn = c[ht][r] * fast_sigmoid(gf + forget_bias) + fast_sigmoid(gi) * fast_tanh(gj);
-          const float hn = fast_tanh(cn) * fast_sigmoid(go);
+          const float si = fast_sigmoid(gi), tj = fast_tanh(gj), sf = fast_sigmoid(gf + forget_bias);
+          const float so = fast_sigmoid(go);
+          const float cn = c[ht][r] * sf + si * tj;
+          const float hn = fast_tanh(cn) * so;
           c[ht][r] = cn;
           const int row = crow(r, rh_);
           const int col = ht * 32 + cj_;
           stage[row * D + (col ^ row)] = hn;  // for the next step's A operand
           const int64_t grow = row0 + row;
+          if (SAVE && grow < n) {
+            float* gp = gates_out + (grow * t + ts) * (int64_t)(4 * D) + col;
+            gp[0] = si;
+            gp[D] = tj;
+            gp[2 * D] = sf;
+            gp[3 * D] = so;
+            c_out[(grow * t + ts) * (int64_t)D + col] = cn;
+          }
           if (grow < n) {
             float hv = hn;
             if (drop) hv *= drop[grow * (int64_t)t * D + (int64_t)ts * D + col];
@@ -605,14 +618,14 @@ namespace sagnn {
 
 bool lstm_mfma_supported(int d) { return d == 32 || d == 64; }
 
-template <int D>
+template <int D, bool SAVE>
 static int launch_lstm_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t,
                             const float* W, const float* b, float forget_bias, const float* drop,
-                            float* h, int64_t ld_h, hipStream_t s) {
+                            float* h, int64_t ld_h, float* gates_out, float* c_out, hipStream_t s) {
   const size_t lds = (size_t)(2 * D * 4 * D + 4 * kRowsPerWave * D) * sizeof(float);
   static bool configured = false;
   if (!configured) {
-    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_mfma_kernel<D>),
+    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_mfma_kernel<D, SAVE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
@@ -624,17 +637,20 @@ static int launch_lstm_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t 
   const int64_t n_tiles = (n + kRowsPerBlock - 1) / kRowsPerBlock;
   const int64_t blocks = n_tiles < cus ? n_tiles : cus;
   ProfileScope prof(kProfLstm, s, n, t);
-  hipLaunchKernelGGL(lstm_fwd_mfma_kernel<D>, dim3((unsigned)blocks), dim3(kBlock), lds, s, x, ld_n, ld_t,
-                     n, t, W, b, forget_bias, drop, h, ld_h, n_tiles);
+  hipLaunchKernelGGL((lstm_fwd_mfma_kernel<D, SAVE>), dim3((unsigned)blocks), dim3(kBlock), lds, s, x, ld_n, ld_t,
+                     n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, n_tiles);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
 
 int lstm_fwd_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
                   const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
-                  hipStream_t s) {
-  if (d == 64) return launch_lstm_mfma<64>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, s);
-  if (d == 32) return launch_lstm_mfma<32>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, s);
+                  float* gates_out, float* c_out, hipStream_t s) {
+  const bool save = gates_out != nullptr;
+  if (d == 64 && save) return launch_lstm_mfma<64, true>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, s);
+  if (d == 64) return launch_lstm_mfma<64, false>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, nullptr, nullptr, s);
+  if (d == 32 && save) return launch_lstm_mfma<32, true>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, s);
+  if (d == 32) return launch_lstm_mfma<32, false>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, nullptr, nullptr, s);
   return fail(SAGNN_ERR_DIM, "MFMA LSTM supports d = 32 or 64, got %d", d);
 }
 

@@ -324,3 +324,42 @@ def dense_tn(x: torch.Tensor, g: torch.Tensor, dW: torch.Tensor, db: torch.Tenso
                                          _vec("dW", dW, din * dout), None if db is None else _vec("db", db, dout),
                                          _stream()))
     return dW
+
+
+def mul(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None):
+    """out = a * b element-wise (sagnn_mul_f32); contiguous float32 tensors of equal size."""
+    if out is None:
+        out = torch.empty_like(a)
+    for name, x in (("a", a), ("b", b), ("out", out)):
+        if x.dtype != torch.float32 or not x.is_contiguous() or x.numel() != a.numel():
+            raise ValueError(f"{name}: need contiguous float32 tensors of equal size")
+    check(_lib.load().sagnn_mul_f32(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _stream()))
+    return out
+
+
+class Adam:
+    """tf.train.AdamOptimizer with the reference's staircase exponential decay and L2 weights
+    (model.py:245-250): state per parameter tensor, one sagnn_adam_step_f32 launch each."""
+
+    def __init__(self, params: dict, lr: float, decay: float = 1.0, decay_step: int = 1, reg: float = 0.0,
+                 reg_names=(), beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
+        self.params = params
+        self.lr0, self.decay, self.decay_step, self.reg = lr, decay, max(int(decay_step), 1), reg
+        self.reg_names = set(reg_names)
+        self.b1, self.b2, self.eps = beta1, beta2, eps
+        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.global_step = 0
+
+    def step(self, grads: dict):
+        lr = self.lr0 * self.decay ** (self.global_step // self.decay_step)     # staircase=True
+        self.global_step += 1
+        lib = _lib.load()
+        for k, g in grads.items():
+            if g is None:
+                continue
+            p = self.params[k]
+            g = g.contiguous()
+            check(lib.sagnn_adam_step_f32(p.data_ptr(), g.data_ptr(), self.m[k].data_ptr(), self.v[k].data_ptr(),
+                                          p.numel(), lr, self.b1, self.b2, self.eps,
+                                          self.reg if k in self.reg_names else 0.0, self.global_step, _stream()))

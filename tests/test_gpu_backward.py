@@ -70,3 +70,80 @@ def test_autograd_function_end_to_end(dev):
     s = float(tu.grad.abs().max())
     np.testing.assert_allclose(pu.grad.cpu().numpy(), tu.grad.numpy(), rtol=2e-4, atol=1e-5 * s)
     np.testing.assert_allclose(pi.grad.cpu().numpy(), ti.grad.numpy(), rtol=2e-4, atol=1e-5 * s)
+
+
+@pytest.mark.parametrize("d,t,n,heads", [(64, 3, 300, 16), (32, 2, 130, 16), (64, 1, 70, 16), (64, 5, 97, 4)])
+def test_interval_fusion_backward_vs_autograd(dev, d, t, n, heads):
+    """Every gradient of the fusion (x and all ten parameter tensors) against float64 autograd."""
+    from sa_gnn_amd import autograd as ag
+    rng = np.random.default_rng(d + t + n)
+    x = rng.standard_normal((n, t, d)).astype(np.float32)
+    p = O.init_fusion_params(d, rng)
+    gout = rng.standard_normal((n, d)).astype(np.float32)
+    # oracle
+    tx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    out = O.torch_interval_fusion(tx, tp, heads)
+    (out * torch.tensor(gout, dtype=torch.float64)).sum().backward()
+    # HIP path; x given as a [t, n, d] storage viewed [n, t, d] (the exchange layout)
+    xd = torch.from_numpy(np.ascontiguousarray(x.transpose(1, 0, 2))).to(dev).permute(1, 0, 2).requires_grad_(True)
+    pd = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in p.items()}
+    got = ag.interval_fusion(xd, pd, heads)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), out.detach().numpy(), rtol=1e-4, atol=2e-5)
+    got.backward(torch.from_numpy(gout).to(dev))
+
+    def check(name, a, b):
+        a, b = a.detach().cpu().numpy().astype(np.float64), b.detach().numpy()
+        # relative bar 1e-4 plus an absolute floor: some gradients are analytically ~0 (a key bias
+        # shifts every score of a row alike; only the 1e-8 in the normaliser breaks the symmetry),
+        # what remains of them is fp32 accumulation noise over n*t rows
+        tol = 1e-4 * np.abs(b) + max(2e-5 * np.abs(b).max(), 5e-6)
+        bad = np.abs(a - b) > tol
+        assert not bad.any(), f"{name}: {bad.sum()}/{bad.size} off, worst {np.abs(a - b)[bad].max():.3e} (scale {np.abs(b).max():.3e})"
+
+    check("dx", xd.grad, tx.grad)
+    for k in p:
+        check("d" + k, pd[k].grad, tp[k].grad)
+
+
+def test_interval_fusion_backward_with_output_dropout(dev):
+    """DropoutWrapper(output_keep_prob): the mask scales the emitted h only; gradients follow."""
+    from sa_gnn_amd import autograd as ag
+    rng = np.random.default_rng(77)
+    n, t, d, heads = 150, 3, 64, 16
+    x = rng.standard_normal((n, t, d)).astype(np.float32)
+    p = O.init_fusion_params(d, rng)
+    scale = ((rng.random((n, t, d)) < 0.5) * 2.0).astype(np.float32)
+    tx = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    tp = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in p.items()}
+    h = O.torch_basic_lstm(tx, tp["lstm_W"], tp["lstm_b"]) * torch.tensor(scale, dtype=torch.float64)
+    out = O.torch_mhsa_mean(O.torch_layer_norm_td(h, tp["ln_gamma"], tp["ln_beta"]), tp["Wq"], tp["bq"], tp["Wk"],
+                            tp["bk"], tp["Wv"], tp["bv"], heads)
+    out.square().sum().backward()
+    xd = torch.from_numpy(x).to(dev).requires_grad_(True)
+    pd = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in p.items()}
+    got = ag.interval_fusion(xd, pd, heads, drop_scale=torch.from_numpy(scale).to(dev))
+    np.testing.assert_allclose(got.detach().cpu().numpy(), out.detach().numpy(), rtol=1e-4, atol=2e-5)
+    got.square().sum().backward()
+    for name, a, b in [("dx", xd.grad, tx.grad)] + [("d" + k, pd[k].grad, tp[k].grad) for k in p]:
+        a, b = a.cpu().numpy().astype(np.float64), b.numpy()
+        tol = 1e-4 * np.abs(b) + max(2e-5 * np.abs(b).max(), 2e-5)   # floor: see the test above
+        assert (np.abs(a - b) <= tol).all(), name
+
+
+def test_adam_step_matches_tf_formula(dev):
+    from sa_gnn_amd import ops
+    rng = np.random.default_rng(1)
+    p0 = rng.standard_normal(1000).astype(np.float32)
+    params = {"w": torch.from_numpy(p0.copy()).to(dev)}
+    opt = ops.Adam(params, lr=1e-2, decay=0.96, decay_step=2, reg=1e-2, reg_names={"w"})
+    p, m, v = p0.astype(np.float64), np.zeros(1000), np.zeros(1000)
+    for step in range(1, 6):
+        g = rng.standard_normal(1000).astype(np.float32)
+        opt.step({"w": torch.from_numpy(g).to(dev)})
+        lr = 1e-2 * 0.96 ** ((step - 1) // 2)
+        gg = g + 2 * 1e-2 * p
+        m = 0.9 * m + 0.1 * gg
+        v = 0.999 * v + 0.001 * gg * gg
+        p = p - lr * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step) * m / (np.sqrt(v) + 1e-8)
+    np.testing.assert_allclose(params["w"].cpu().numpy(), p, rtol=1e-4, atol=1e-5)
