@@ -278,6 +278,20 @@ int sagnn_lstm_bwd_step_f32(const float* gates, const float* cell, const float* 
                             const float* drop_scale, const float* dh_rec, int64_t ld_dhr, const float* dc_in,
                             float* dgates, float* dc_out, int64_t n, int t, int d, int ts, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Prediction head (reference model.py:156-173). The masked sum of item /
+ * position embeddings (model.py:161-162) is sagnn_spmm_f32 on a per-batch CSR (row = batch slot,
+ * columns = the unmasked sequence entries, leaky = 1); layer_norm and the length-1 MHSA are
+ * sagnn_layernorm_td_f32 / sagnn_mhsa_mean_f32 with t = 1; what is left:
+ *   sagnn_leaky_add_f32:  out = max(leaky*a, a) + b      (model.py:166; b nullable)
+ *   sagnn_pair_score_f32: preds[e] = <U[uids[e]], I[iids[e]]> + <leaky(S[locs[e]]), A[iids[e]]>
+ *                         (model.py:169-173; S/A/locs NULL drops the second term)
+ * -------------------------------------------------------------------------------- */
+int sagnn_leaky_add_f32(const float* a, const float* b, float* out, float leaky, int64_t count, void* stream);
+int sagnn_pair_score_f32(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* S, int64_t lds,
+                         const float* A, int64_t lda, const int32_t* uids, const int32_t* iids,
+                         const int32_t* locs, float leaky, float* out, int64_t n_pairs, int d, void* stream);
+
 /* out[i] = a[i] * b[i] (dropout scaling of the emitted LSTM output, model.py:139). */
 int sagnn_mul_f32(const float* a, const float* b, float* out, int64_t count, void* stream);
 

@@ -328,3 +328,44 @@ def torch_interval_fusion(x, p: dict, heads: int):
     h = torch_basic_lstm(x, p["lstm_W"], p["lstm_b"], 1.0)
     y = torch_layer_norm_td(h, p["ln_gamma"], p["ln_beta"], 1e-12)
     return torch_mhsa_mean(y, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], heads)
+
+
+# ----------------------------------------------------------------------------------------------
+# Prediction head and metrics: model.py:156-173, 484-510
+# ----------------------------------------------------------------------------------------------
+
+
+def prediction_head(final_user, final_item, pos_embed, ln_params, att_params, uids, iids, sequence, mask,
+                    ulocs_seq, heads: int, leaky: float):
+    """model.py:156-173. ln_params: list of (gamma, beta) in creation order — [0] item-sequence
+    token, [1] position token, [2 + i] attention layer i; att_params: list of dicts Wq..bv.
+    The sequence is collapsed to ONE token per batch slot by the masked sums (:161-162), so every
+    attention layer runs on length-1 sequences."""
+    m = mask[:, None, :].astype(final_item.dtype)                                    # [B, 1, L]
+    seq = m @ final_item[sequence]                                                    # [B, 1, d]
+    pos = m @ np.broadcast_to(pos_embed[None, :, :], (mask.shape[0],) + pos_embed.shape)
+    sb = layer_norm_td(seq, *ln_params[0]) + layer_norm_td(pos, *ln_params[1])
+    att = sb
+    for i, p in enumerate(att_params):
+        a1 = mhsa(layer_norm_td(att, *ln_params[2 + i]), p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], heads)
+        att = leaky_relu(a1, leaky) + att
+    att_user = att.sum(axis=1)                                                        # [B, d]
+    pck_u, pck_i = final_user[uids], final_item[iids]
+    preds = (pck_u * pck_i).sum(-1)
+    return preds + (leaky_relu(att_user[ulocs_seq], leaky) * pck_i).sum(-1)
+
+
+def calc_res(preds, tem_tst, tst_locs, shoot: int = 10):
+    """Recommender.calcRes (model.py:484-510), the reference's own loop: Python's stable sort with
+    reverse=True keeps the original order among equal scores, and the positive is the LAST
+    candidate, so it loses ties. Returns (hit@shoot, ndcg@shoot, hit@5, ndcg@5, hit@20, ndcg@20)."""
+    out = [0.0] * 6
+    for j in range(preds.shape[0]):
+        predvals = list(zip(preds[j], tst_locs[j]))
+        predvals.sort(key=lambda x: x[0], reverse=True)
+        for slot, k in enumerate((shoot, 5, 20)):
+            top = [x[1] for x in predvals[:k]]
+            if tem_tst[j] in top:
+                out[2 * slot] += 1
+                out[2 * slot + 1] += float(np.reciprocal(np.log2(top.index(tem_tst[j]) + 2)))
+    return tuple(out)

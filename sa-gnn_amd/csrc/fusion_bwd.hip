@@ -259,7 +259,79 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   p[i] = pv - lr_t * mv / (sqrtf(vv) + eps);
 }
 
+// out[i] = max(leaky*a[i], a[i]) + b[i]   (b nullable)
+__global__ void leaky_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                 float leaky, int64_t count) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const float x = a[i];
+  out[i] = fmaxf(leaky * x, x) + (b ? b[i] : 0.f);
+}
+
+// preds[e] = <U[uid_e], I[iid_e]> + <leaky(S[loc_e]), A[iid_e]>   (second term optional)
+// One wavefront per pair group: LPR = d/4 lanes per pair, float4 per lane.
+__global__ void pair_score_kernel(const float* __restrict__ U, int64_t ldu, const float* __restrict__ I, int64_t ldi,
+                                  const float* __restrict__ S, int64_t lds_, const float* __restrict__ A, int64_t lda,
+                                  const int32_t* __restrict__ uids, const int32_t* __restrict__ iids,
+                                  const int32_t* __restrict__ locs, float leaky, float* __restrict__ out,
+                                  int64_t n_pairs, int d) {
+  const int lpr = d >> 2;                       // lanes per pair (power of two <= 64)
+  const int lane = threadIdx.x & 63;
+  const int ppw = 64 / lpr;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t e = wave * ppw + lane / lpr;
+  const int col = (lane % lpr) * 4;
+  float acc = 0.f;
+  if (e < n_pairs) {
+    const int64_t u = uids[e], it = iids[e];
+    const float4 a = *reinterpret_cast<const float4*>(U + u * ldu + col);
+    const float4 b = *reinterpret_cast<const float4*>(I + it * ldi + col);
+    acc = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    if (S) {
+      const float4 s = *reinterpret_cast<const float4*>(S + (int64_t)locs[e] * lds_ + col);
+      const float4 c = *reinterpret_cast<const float4*>(A + it * lda + col);
+      acc += fmaxf(leaky * s.x, s.x) * c.x + fmaxf(leaky * s.y, s.y) * c.y + fmaxf(leaky * s.z, s.z) * c.z +
+             fmaxf(leaky * s.w, s.w) * c.w;
+    }
+  }
+  for (int off = 1; off < lpr; off <<= 1) acc += __shfl_xor(acc, off);
+  if (e < n_pairs && (lane % lpr) == 0) out[e] = acc;
+}
+
 }  // namespace
+
+extern "C" int sagnn_leaky_add_f32(const float* a, const float* b, float* out, float leaky, int64_t count,
+                                   void* stream) {
+  if (!a || !out) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (count <= 0) return SAGNN_OK;
+  const int64_t blocks = (count + kBlock - 1) / kBlock;
+  if (blocks > INT32_MAX) return sagnn::fail(SAGNN_ERR_ARG, "grid too large");
+  hipLaunchKernelGGL(leaky_add_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), a,
+                     b, out, leaky, count);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_pair_score_f32(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* S,
+                                    int64_t lds, const float* A, int64_t lda, const int32_t* uids,
+                                    const int32_t* iids, const int32_t* locs, float leaky, float* out,
+                                    int64_t n_pairs, int d, void* stream) {
+  if (!U || !I || !uids || !iids || !out) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if ((S == nullptr) != (A == nullptr) || (S && !locs)) return sagnn::fail(SAGNN_ERR_NULL, "S, A and locs go together");
+  const int lpr = d / 4;
+  if (d < 4 || d > 256 || (d & 3) || (lpr & (lpr - 1)))
+    return sagnn::fail(SAGNN_ERR_DIM, "d = %d: need 4 * a power of two, <= 256", d);
+  if ((ldu & 3) || (ldi & 3) || (S && ((lds & 3) || (lda & 3)))) return sagnn::fail(SAGNN_ERR_ALIGN, "strides must be multiples of 4");
+  if (n_pairs <= 0) return SAGNN_OK;
+  const int ppw = 64 / lpr;
+  const int64_t waves = (n_pairs + ppw - 1) / ppw;
+  const int64_t blocks = (waves + 3) / 4;
+  if (blocks > INT32_MAX) return sagnn::fail(SAGNN_ERR_ARG, "grid too large");
+  hipLaunchKernelGGL(pair_score_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), U,
+                     ldu, I, ldi, S, lds, A, lda, uids, iids, locs, leaky, out, n_pairs, d);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
 
 extern "C" int sagnn_mul_f32(const float* a, const float* b, float* out, int64_t count, void* stream) {
   if (!a || !b || !out) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");

@@ -11,6 +11,7 @@ prediction head, SSL loss, samplers and optimiser around it are §8(f) "next" ro
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import ops
@@ -129,7 +130,21 @@ class Recommender:
         for _ in range(2 * T * args.gnn_layer):
             NNs.defineRandomNameParam([d, d], reg=True)
         self._define_fusion_params()
+        self._define_head_params()
         return self.forward()
+
+    def _define_head_params(self):
+        """Variables of the prediction head in the reference's creation order (model.py:158-166):
+        att_layer MHSA instances, then layer_norm gamma/beta pairs LayerNorm_2 (item-sequence
+        token), LayerNorm_3 (position token), LayerNorm_4.. (one per attention layer)."""
+        d = args.latdim
+        self.multihead_self_attention_sequence = [MultiHeadSelfAttention(d, args.num_attention_heads)
+                                                  for _ in range(args.att_layer)]
+        self.head_ln = []
+        for i in range(2 + args.att_layer):
+            tag = "LayerNorm_%d" % (2 + i)
+            self.head_ln.append((NNs.defineParam(tag + "_gamma", [d], initializer="ones"),
+                                 NNs.defineParam(tag + "_beta", [d], initializer="zeros")))
 
     def forward(self):
         """Re-runs the hot path with the current parameters (what every sess.run recomputes)."""
@@ -155,6 +170,108 @@ class Recommender:
 
         self._graph = graph
         return replay
+
+    # ------------------------------------------------------------------ prediction head
+    def _masked_sum_plans(self, sequence, mask):
+        """Per-batch CSRs for the masked sums of model.py:161-162: row b lists the unmasked
+        entries of the batch slot's sequence (item ids, and their positions)."""
+        sequence = np.asarray(sequence, dtype=np.int64)
+        keep = np.asarray(mask) != 0
+        B, L = keep.shape
+        rowptr = np.zeros(B + 1, dtype=np.int32)
+        np.cumsum(keep.sum(1), out=rowptr[1:])
+        items = sequence[keep].astype(np.int32)
+        pos = np.broadcast_to(np.arange(L, dtype=np.int32), (B, L))[keep]
+        pi = ops.SpmmPlan(rowptr, items, B, args.item, device=self.device, validate=False)
+        pp = ops.SpmmPlan(rowptr, np.ascontiguousarray(pos), B, L, device=self.device, validate=False)
+        return pi, pp
+
+    def predict(self, uids, iids, sequence, mask, uLocs_seq):
+        """self.preds of the reference (model.py:156-173) for one batch, on the cached
+        final_user_vector / final_item_vector. sequence/mask: [args.batch, pos_length]."""
+        heads, leaky = args.num_attention_heads, NNs.leaky
+        fu, fi = self.final_user_vector, self.final_item_vector
+        pi, pp = self._masked_sum_plans(sequence, mask)
+        seq_tok = ops.spmm(pi, fi, 1.0)                                   # [B, d] masked item sum
+        pos_tok = ops.spmm(pp, self.posEmbed.detach(), 1.0)               # [B, d] masked position sum
+        B, d = seq_tok.shape
+        ln = lambda x, gb: ops.layernorm_td(x.view(B, 1, d), gb[0].detach(), gb[1].detach()).view(B, d)
+        att = ops.leaky_add(ln(seq_tok, self.head_ln[0]), ln(pos_tok, self.head_ln[1]), 1.0)
+        for i, mh in enumerate(self.multihead_self_attention_sequence):
+            a1 = mh.attention_mean(ln(att, self.head_ln[2 + i]).view(B, 1, d))      # length-1 sequence
+            att = ops.leaky_add(a1, att, leaky)
+        as_i32 = lambda v: torch.as_tensor(np.asarray(v, dtype=np.int32), device=self.device)
+        return ops.pair_score(fu, fi, as_i32(uids), as_i32(iids), S=att, A=fi, locs=as_i32(uLocs_seq), leaky=leaky)
+
+    def sampleTestBatch(self, batIds, labelMat=None):
+        """reference model.py:384-428: args.testSize-1 pre-drawn negatives from test_dict
+        (1-indexed user keys and item ids) plus the held-out positive LAST; the user's whole
+        sequence, right-aligned into pos_length slots."""
+        batch = len(batIds)
+        temTst = self.handler.tstInt[batIds]
+        uLocs, iLocs, uLocs_seq, tstLocs = [], [], [], []
+        sequence = np.zeros((args.batch, args.pos_length), dtype=np.int64)
+        mask = np.zeros((args.batch, args.pos_length), dtype=np.float32)
+        val_list = [None] * args.batch
+        for i in range(batch):
+            u = int(batIds[i])
+            if args.test:
+                posloc = temTst[i]
+                posset = self.handler.sequence[u]
+            else:
+                posloc = self.handler.sequence[u][-1]
+                val_list[i] = posloc
+                posset = self.handler.sequence[u][:-1]
+            neg = np.array(self.handler.test_dict[u + 1][:args.testSize - 1]) - 1
+            locset = np.concatenate((neg, np.array([posloc])))
+            tstLocs.append(locset)
+            uLocs.extend([u] * len(locset))
+            iLocs.extend(int(x) for x in locset)
+            uLocs_seq.extend([i] * len(locset))
+            if len(posset) == 0:
+                continue
+            if len(posset) <= args.pos_length:
+                sequence[i, -len(posset):] = posset
+                mask[i, -len(posset):] = 1
+            else:
+                sequence[i] = posset[-args.pos_length:]
+                mask[i] = 1
+        return uLocs, iLocs, temTst, tstLocs, sequence, mask, uLocs_seq, val_list
+
+    @staticmethod
+    def calcRes(preds, temTst, tstLocs, shoot=None):
+        """reference model.py:484-510 vectorised: a stable descending sort keeps the candidate
+        order among ties and the positive is the last candidate, so it loses them."""
+        shoot = args.shoot if shoot is None else shoot
+        preds = np.asarray(preds)
+        order = np.argsort(-preds, axis=1, kind="stable")
+        res = []
+        for k in (shoot, 5, 20):
+            hit = ndcg = 0.0
+            for j in range(preds.shape[0]):
+                top = np.asarray(tstLocs[j])[order[j, :k]]
+                w = np.flatnonzero(top == temTst[j])
+                if w.size:
+                    hit += 1
+                    ndcg += 1.0 / np.log2(w[0] + 2)
+            res += [hit, ndcg]
+        return tuple(res)
+
+    def testEpoch(self):
+        """reference model.py:430-482. The hot path is evaluated ONCE (parameters are frozen and
+        keepRate = 1 during testing, model.py:458) instead of once per batch."""
+        self.forward()
+        ids = self.handler.tstUsrs
+        num = len(ids)
+        tot = np.zeros(6)
+        for st in range(0, num, args.batch):
+            batIds = ids[st:st + args.batch]
+            uLocs, iLocs, temTst, tstLocs, sequence, mask, uLocs_seq, val_list = self.sampleTestBatch(batIds)
+            preds = self.predict(uLocs, iLocs, sequence, mask, uLocs_seq).cpu().numpy()
+            target = temTst if args.test else val_list
+            tot += np.array(self.calcRes(preds.reshape(len(batIds), -1), target, tstLocs))
+        return {"HR": tot[0] / num, "NDCG": tot[1] / num, "HR5": tot[2] / num, "NDCG5": tot[3] / num,
+                "HR20": tot[4] / num, "NDCG20": tot[5] / num}
 
     # ------------------------------------------------------------------ model construction
     def prepareModel(self):

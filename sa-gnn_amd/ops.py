@@ -363,3 +363,30 @@ class Adam:
             check(lib.sagnn_adam_step_f32(p.data_ptr(), g.data_ptr(), self.m[k].data_ptr(), self.v[k].data_ptr(),
                                           p.numel(), lr, self.b1, self.b2, self.eps,
                                           self.reg if k in self.reg_names else 0.0, self.global_step, _stream()))
+
+
+def leaky_add(a: torch.Tensor, b: torch.Tensor | None, leaky: float, out: torch.Tensor | None = None):
+    """out = max(leaky*a, a) + b (sagnn_leaky_add_f32); contiguous float32."""
+    if out is None:
+        out = torch.empty_like(a)
+    for name, x in (("a", a), ("b", b), ("out", out)):
+        if x is not None and (x.dtype != torch.float32 or not x.is_contiguous() or x.numel() != a.numel()):
+            raise ValueError(f"{name}: need contiguous float32 tensors of equal size")
+    check(_lib.load().sagnn_leaky_add_f32(a.data_ptr(), _ptr(b), out.data_ptr(), float(leaky), a.numel(), _stream()))
+    return out
+
+
+def pair_score(U: torch.Tensor, I: torch.Tensor, uids: torch.Tensor, iids: torch.Tensor, S: torch.Tensor | None = None,
+               A: torch.Tensor | None = None, locs: torch.Tensor | None = None, leaky: float = 1.0):
+    """preds[e] = <U[uids[e]], I[iids[e]]> + <leaky(S[locs[e]]), A[iids[e]]> (sagnn_pair_score_f32)."""
+    d = int(U.shape[1])
+    n = int(uids.numel())
+    out = torch.empty(n, dtype=torch.float32, device=U.device)
+    for name, x in (("uids", uids), ("iids", iids), ("locs", locs)):
+        if x is not None and (x.dtype != torch.int32 or not x.is_contiguous() or x.numel() != n):
+            raise ValueError(f"{name}: need a contiguous int32 tensor of {n} elements")
+    check(_lib.load().sagnn_pair_score_f32(
+        U.data_ptr(), _f32_rows("U", U, d), I.data_ptr(), _f32_rows("I", I, d), _ptr(S),
+        0 if S is None else _f32_rows("S", S, d), _ptr(A), 0 if A is None else _f32_rows("A", A, d),
+        uids.data_ptr(), iids.data_ptr(), _ptr(locs), float(leaky), out.data_ptr(), n, d, _stream()))
+    return out

@@ -6,9 +6,9 @@ import torch
 
 from oracle import selfgnn_oracle as O
 
-pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.gpu
 def test_recommender_hot_path_vs_oracle(dev):
     from sa_gnn_amd import synthetic
     from sa_gnn_amd.DataHandler import DataHandler
@@ -56,6 +56,7 @@ def test_recommender_hot_path_vs_oracle(dev):
         rec.messagePropagate(NNs.params["iEmbed"][0], rec.subAdj[0], "item")
 
 
+@pytest.mark.gpu
 def test_graph_replay_matches_eager(dev):
     """hipGraph capture of the whole hot path: replays track parameter updates and match eager."""
     from sa_gnn_amd import synthetic
@@ -75,3 +76,64 @@ def test_graph_replay_matches_eager(dev):
     fu_e, fi_e = rec.forward()
     torch.testing.assert_close(fu_g, fu_e, rtol=0, atol=0)
     torch.testing.assert_close(fi_g, fi_e, rtol=0, atol=0)
+
+
+@pytest.mark.gpu
+def test_prediction_head_and_metrics_vs_oracle(dev):
+    """Prediction head (model.py:156-173) and HR/NDCG (model.py:484-510) against the oracle,
+    on a synthetic dataset with tst_int / test_dict in the reference's format."""
+    import numpy as np
+    from sa_gnn_amd import synthetic
+    from sa_gnn_amd.DataHandler import DataHandler
+    from sa_gnn_amd.Params import args
+    from sa_gnn_amd.Utils import NNLayers as NNs
+    from sa_gnn_amd.model import Recommender
+    rng = np.random.default_rng(12)
+    args.graphNum, args.gnn_layer, args.latdim, args.leaky = 3, 2, 64, 0.5
+    args.att_layer, args.batch, args.pos_length, args.testSize, args.test = 2, 64, 20, 50, True
+    U, I = 150, 120
+    tmt = synthetic.make_trn_mat_time(U, I, [1500, 1400, 1300])
+    seq = synthetic.make_sequence(tmt)
+    tst_int = [int(rng.integers(0, I)) if u % 3 else None for u in range(U)]
+    test_dict = {u + 1: list(rng.integers(1, I + 1, size=60)) for u in range(U)}      # 1-indexed
+    handler = DataHandler.from_memory(tmt, seq, tst_int, test_dict)
+    rec = Recommender(dev, handler)
+    rec.prepareModel()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    with torch.no_grad():
+        for name in list(NNs.params):
+            if name.endswith("bias") or name.endswith("beta"):
+                NNs.params[name].copy_(0.1 * torch.randn(NNs.params[name].shape, generator=g))
+        for k in ("uEmbed", "iEmbed", "posEmbed"):
+            NNs.params[k].mul_(30)
+    res = rec.testEpoch()
+    # oracle: same batches through the numpy restatement
+    cpu = lambda t: t.detach().cpu().numpy()
+    fu, fi = cpu(rec.final_user_vector), cpu(rec.final_item_vector)
+    ln_params = [(cpu(gm), cpu(bt)) for gm, bt in rec.head_ln]
+    att_params = [{k: cpu(v) for k, v in mh.weights().items()} for mh in rec.multihead_self_attention_sequence]
+    ids = handler.tstUsrs
+    tot = np.zeros(6)
+    for st in range(0, len(ids), args.batch):
+        bat = ids[st:st + args.batch]
+        uL, iL, temTst, tstLocs, sequence, mask, uLs, _ = rec.sampleTestBatch(bat)
+        want = O.prediction_head(fu, fi, cpu(NNs.params["posEmbed"]), ln_params, att_params, np.array(uL), np.array(iL),
+                                 sequence, mask, np.array(uLs), 16, 0.5)
+        got = rec.predict(uL, iL, sequence, mask, uLs).cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+        o = O.calc_res(want.reshape(len(bat), -1), temTst, tstLocs, shoot=10)
+        mine = rec.calcRes(want.reshape(len(bat), -1), temTst, tstLocs, shoot=10)
+        np.testing.assert_allclose(mine, o, rtol=1e-12)
+        tot += np.array(o)
+    assert abs(res["HR"] - tot[0] / len(ids)) <= 2.0 / len(ids) and 0 < res["HR"] <= 1
+    assert abs(res["NDCG"] - tot[1] / len(ids)) <= 2.0 / len(ids)
+
+
+def test_calc_res_tie_order():
+    """Ties: the positive is the last candidate and a stable descending sort keeps it last."""
+    from sa_gnn_amd.model import Recommender
+    preds = np.array([[1.0, 1.0, 1.0, 0.5], [0.1, 0.9, 0.9, 0.9]])
+    tst_locs = [np.array([7, 8, 9, 3]), np.array([4, 5, 6, 2])]
+    got = Recommender.calcRes(preds, [9, 2], tst_locs, shoot=2)
+    want = O.calc_res(preds, [9, 2], tst_locs, shoot=2)
+    assert got == want and got[0] == 0.0          # neither positive makes the top-2
