@@ -62,6 +62,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
     p.add_argument("--tuning", default="", help="short,long,chunk override for the SpMM plan")
+    p.add_argument("--intervals-per-gpu", type=int, default=0, help="override (synthetic workload only)")
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="gloo = rehearsal of the N>1 pipeline on ONE GPU (every rank uses cuda:0, collectives "
+                        "staged through host memory); never a performance run")
     p.add_argument("--graph", action="store_true",
                    help="N=1: time a hipGraph replay of the step (launch-bound small workloads); the "
                         "per-kernel event timing then comes from an extra eager pass before it")
@@ -79,13 +83,21 @@ def main():
     from sa_gnn_amd import _lib, ops, synthetic
     from sa_gnn_amd.parallel import IntervalSharding, RowShardExchange, exchange_to_row_shards, gather_fused
 
+    rehearsal = world > 1 and a.dist_backend == "gloo"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     lib = _lib.load()
 
     w = dict(WORKLOADS[a.workload])
+    if a.intervals_per_gpu > 0 and "t_per_gpu" in w:
+        w["t_per_gpu"] = a.intervals_per_gpu
     U, I = int(w["users"] * a.scale), int(w["items"] * a.scale)
     d, L, heads = w["d"], w["layers"], 16
     T = w["t_per_gpu"] * world if "t_per_gpu" in w else w["t_total"]
@@ -129,27 +141,29 @@ def main():
     # travels over xGMI under the next interval's SpMMs (--exchange allgather: one blocking
     # all-gather of the stacked outputs instead, for comparison)
     overlap = world > 1 and a.exchange == "alltoall"
-    ex_u = RowShardExchange(sh, U, d, dev) if overlap else None
-    ex_i = RowShardExchange(sh, I, d, dev) if overlap else None
+    comm_dev = torch.device("cpu") if rehearsal else dev          # gloo rehearsal: collectives on host copies
+    ex_u = RowShardExchange(sh, U, d, comm_dev) if overlap else None
+    ex_i = RowShardExchange(sh, I, d, comm_dev) if overlap else None
 
     def step():
         nonlocal fuse_ws
         for j in range(t_loc):
             ops.gnn_interval(plans[j][0], plans[j][1], emb[j][0], emb[j][1], L, 0.5, out_u[j], out_i[j], scr_u, scr_i)
             if overlap and a.stages == "full":
-                ex_u.post(out_u[j])
-                ex_i.post(out_i[j])
+                ex_u.post(out_u[j].to(comm_dev))
+                ex_i.post(out_i[j].to(comm_dev))
         if a.stages == "spmm":
             return
         pending = []
         for x_loc, n_rows, p, ex in ((out_u, U, prm[0], ex_u), (out_i, I, prm[1], ex_i)):
-            x = ex.finish() if overlap else exchange_to_row_shards(x_loc, sh, n_rows, mode=a.exchange)
+            x = ex.finish() if overlap else exchange_to_row_shards(x_loc.to(comm_dev), sh, n_rows, mode=a.exchange)
+            x = x.to(dev)
             need = x.shape[0] * x.shape[1] * d                                   # [T, rows_local, d]
             if fuse_ws.numel() < need:
                 fuse_ws = torch.empty(need, device=dev)
             f = ops.interval_fusion(x.permute(1, 0, 2), p, heads, workspace=fuse_ws)
-            pending.append(gather_fused(f, sh, n_rows, async_op=True))          # users' gather runs under items' fusion
-        state["final"] = [fin() for _, fin in pending]
+            pending.append(gather_fused(f.to(comm_dev), sh, n_rows, async_op=True))   # users' gather runs under items' fusion
+        state["final"] = [fin().to(dev) for _, fin in pending]
 
     def sync():
         torch.cuda.synchronize()
@@ -190,10 +204,10 @@ def main():
         sync()
         elapsed = time.perf_counter() - t1
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=comm_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        te = torch.tensor([local_edges], device=dev, dtype=torch.int64)
+        te = torch.tensor([local_edges], device=comm_dev, dtype=torch.int64)
         dist.all_reduce(te)
         total_edges_once = int(te.item())
     else:
@@ -229,6 +243,9 @@ def main():
         except Exception:
             traffic = None
 
+    checksum = None
+    if "final" in state:                       # identical on every rank and for every N at equal T
+        checksum = [float(f.double().abs().mean()) for f in state["final"]]
     edges_per_step = total_edges_once * 2 * L
     value = edges_per_step * a.steps / elapsed
     result = {
@@ -246,7 +263,7 @@ def main():
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "launches": len(rows_k), "avg_launch_ms": k_ms / max(len(rows_k), 1),
                      "algorithmic_bytes_per_launch": alg_bytes / max(len(rows_k), 1)},
-        "stage_ms_per_step_rank0": stage_ms,
+        "stage_ms_per_step_rank0": stage_ms, "final_abs_mean": checksum,
         "spmm_only_edges_per_sec_rank0": (local_edges * 2 * L) / ((stage_ms["spmm_rows"] + stage_ms["spmm_fixup"]) * 1e-3)
         if stage_ms["spmm_rows"] > 0 else None,
     }
