@@ -57,7 +57,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--workload", default="synthetic-powerlaw-10Mx5M", choices=sorted(WORKLOADS))
     p.add_argument("--scale", type=float, default=1.0, help="shrink users/items/edges (debug only; recorded in config)")
-    p.add_argument("--stages", default="full", choices=["full", "spmm"], help="spmm = time the SpMM stack alone")
+    p.add_argument("--stages", default="full", choices=["full", "spmm", "train"],
+                   help="spmm = time the SpMM stack alone; train = forward + backward + Adam of the hot "
+                        "path (N = 1; loss = sum of the fused embeddings) — not the headline metric")
     p.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-rows", type=int, default=2_000_000)
@@ -165,6 +167,36 @@ def main():
             pending.append(gather_fused(f.to(comm_dev), sh, n_rows, async_op=True))   # users' gather runs under items' fusion
         state["final"] = [fin().to(dev) for _, fin in pending]
 
+    if a.stages == "train":
+        if world != 1:
+            raise SystemExit("--stages train is a single-GPU measurement")
+        from sa_gnn_amd import autograd as ag
+        leaves = {}
+        for j in range(t_loc):
+            leaves[f"u{j}"] = emb[j][0].requires_grad_(True)
+            leaves[f"i{j}"] = emb[j][1].requires_grad_(True)
+        for tag, p in (("U", prm[0]), ("I", prm[1])):
+            for k, v in p.items():
+                if tag == "I" and k in ("lstm_W", "lstm_b"):
+                    continue                              # the cell is shared: one leaf
+                leaves[f"{tag}.{k}"] = v.requires_grad_(True)
+        opt = ops.Adam(leaves, lr=1e-3, decay=0.96, decay_step=19, reg=1e-2,
+                       reg_names=[k for k in leaves if k[0] in "ui"])
+
+        def step():                                       # noqa: F811  (training step replaces the forward step)
+            for v in leaves.values():
+                v.grad = None
+            us, its = [], []
+            for j in range(t_loc):
+                uo, io = ag.gnn_interval(leaves[f"u{j}"], leaves[f"i{j}"], plans[j][0], plans[j][1], L, 0.5)
+                us.append(uo)
+                its.append(io)
+            fu = ag.interval_fusion(torch.stack(us).permute(1, 0, 2), prm[0], heads)
+            fi = ag.interval_fusion(torch.stack(its).permute(1, 0, 2), prm[1], heads)
+            (fu.sum() + fi.sum()).backward()
+            opt.step({k: v.grad for k, v in leaves.items()})
+            state["final"] = [fu.detach(), fi.detach()]
+
     def sync():
         torch.cuda.synchronize()
         if world > 1:
@@ -175,7 +207,7 @@ def main():
     for _ in range(a.warmup):
         step()
     sync()
-    launches_per_step = t_loc * 2 * L * 2 + 8
+    launches_per_step = t_loc * 2 * L * 2 + 8 if a.stages != "train" else t_loc * 2 * L * 4 + 16
     lib.sagnn_profile_enable(a.steps * launches_per_step + 16)
     sync()
     t1 = time.perf_counter()
