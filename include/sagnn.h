@@ -292,6 +292,45 @@ int sagnn_pair_score_f32(const float* U, int64_t ldu, const float* I, int64_t ld
                          const float* A, int64_t lda, const int32_t* uids, const int32_t* iids,
                          const int32_t* locs, float leaky, float* out, int64_t n_pairs, int d, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Training-side operators (reference model.py:169-205, 241-250). All scatter
+ * outputs (dU, dI, dS, dA, dX, dY, dF, dV, dw3, db3, loss) ACCUMULATE with float atomics: zero
+ * them first. Dense gradient rows are [rows, d] contiguous.
+ *   sagnn_pair_score_bwd_f32      backward of sagnn_pair_score_f32 given g [n_pairs]
+ *   sagnn_prod_leaky_sum_f32      s[e] = sum_j leaky(X[uids[e]][j] * Y[iids[e]][j])   (model.py:191,199)
+ *   sagnn_prod_leaky_sum_bwd_f32  its backward
+ *   sagnn_meta_features_f32       m[e] = [F[u]*V[u] | F[u] | V[u]], u = uids[e]      (model.py:179)
+ *   sagnn_meta_features_bwd_f32   its backward
+ *   sagnn_leaky_f32               backward == 0: out = max(leaky*a, a); else out = g * slope(a)
+ *   sagnn_rowdot_sigmoid_f32      w[e] = sigmoid(<A[e, :k], w3> + b3)                 (model.py:182)
+ *   sagnn_rowdot_sigmoid_bwd_f32  dA[e, :k] = dz*w3, dw3 += sum dz*A[e], db3 += sum dz, dz = dw*w*(1-w)
+ *   sagnn_hinge_f32               loss += scale * sum max(0, 1 - S*(pos - neg)), S = wp*sp - wn*sn
+ *                                 (S = 1 when wp is NULL: model.py:244; weighted: model.py:196,202);
+ *                                 writes d(loss)/d pos, neg, wp, wn (each nullable)
+ * -------------------------------------------------------------------------------- */
+int sagnn_pair_score_bwd_f32(const float* U, int64_t ldu, const float* I, int64_t ldi, const float* S, int64_t lds,
+                             const float* A, int64_t lda, const int32_t* uids, const int32_t* iids,
+                             const int32_t* locs, float leaky, const float* g, float* dU, float* dI, float* dS,
+                             float* dA, int64_t n_pairs, int d, void* stream);
+int sagnn_prod_leaky_sum_f32(const float* X, int64_t ldx, const float* Y, int64_t ldy, const int32_t* uids,
+                             const int32_t* iids, float leaky, float* out, int64_t n_pairs, int d, void* stream);
+int sagnn_prod_leaky_sum_bwd_f32(const float* X, int64_t ldx, const float* Y, int64_t ldy, const int32_t* uids,
+                                 const int32_t* iids, float leaky, const float* g, float* dX, float* dY,
+                                 int64_t n_pairs, int d, void* stream);
+int sagnn_meta_features_f32(const float* F, int64_t ldf, const float* V, int64_t ldv, const int32_t* uids,
+                            float* out, int64_t n, int d, void* stream);
+int sagnn_meta_features_bwd_f32(const float* F, int64_t ldf, const float* V, int64_t ldv, const int32_t* uids,
+                                const float* dm, float* dF, float* dV, int64_t n, int d, void* stream);
+int sagnn_leaky_f32(const float* a, const float* g, float* out, float leaky, int64_t count, int backward,
+                    void* stream);
+int sagnn_rowdot_sigmoid_f32(const float* A, int64_t lda, const float* w3, const float* b3, float* out, int64_t n,
+                             int k, void* stream);
+int sagnn_rowdot_sigmoid_bwd_f32(const float* A, int64_t lda, const float* w3, const float* w, const float* dw,
+                                 float* dA, int64_t ldda, float* dw3, float* db3, int64_t n, int k, void* stream);
+int sagnn_hinge_f32(const float* pos, const float* neg, const float* wp, const float* wn, const float* sp,
+                    const float* sn, float scale, float* loss, float* dpos, float* dneg, float* dwp, float* dwn,
+                    int64_t n, void* stream);
+
 /* out[i] = a[i] * b[i] (dropout scaling of the emitted LSTM output, model.py:139). */
 int sagnn_mul_f32(const float* a, const float* b, float* out, int64_t count, void* stream);
 

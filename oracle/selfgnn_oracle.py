@@ -369,3 +369,69 @@ def calc_res(preds, tem_tst, tst_locs, shoot: int = 10):
                 out[2 * slot] += 1
                 out[2 * slot + 1] += float(np.reciprocal(np.log2(top.index(tem_tst[j]) + 2)))
     return tuple(out)
+
+
+def torch_train_loss(P: dict, adj_list, tp_list, batch: dict, cfg: dict):
+    """The reference's training objective for one step (model.py:104-205, 241-246) in differentiable
+    torch float64, WITHOUT the L2 term (that one is args.reg * sum of squares of the registered
+    parameters, model.py:245). Returns (preLoss, sslloss, final_user, final_item).
+
+    P: uEmbed [T,U,d], iEmbed [T,I,d], posEmbed [L,d], fusion dicts "fuse_u"/"fuse_i" (lstm_W,
+       lstm_b shared), head "ln" list of (gamma, beta) and "att" list of dicts, meta2_W/b, meta3_W/b.
+    batch: uids, iids, uLocs_seq, sequence [B,L], mask [B,L], suids[k], siids[k] (lists), drop_u /
+       drop_i (output-dropout scales [N,T,d] or None).
+    Quirks kept: the halves of every score vector are taken by POSITION (model.py:192-195, 200-201,
+    242-243) although sampleSslBatch interleaves positives and negatives (model.py:331-335)."""
+    import torch
+    T, L, leaky, heads = cfg["T"], cfg["L"], cfg["leaky"], cfg["heads"]
+
+    def lk(x):
+        a = leaky * x
+        return torch.where(a >= x, a, x)
+
+    uv, iv = [], []
+    for k in range(T):
+        u, i = torch_gnn_interval(P["uEmbed"][k], P["iEmbed"][k], adj_list[k], tp_list[k], L, leaky)
+        uv.append(u)
+        iv.append(i)
+
+    def fuse(x, p, drop):
+        h = torch_basic_lstm(x, p["lstm_W"], p["lstm_b"])
+        if drop is not None:
+            h = h * drop
+        return torch_mhsa_mean(torch_layer_norm_td(h, p["ln_gamma"], p["ln_beta"]), p["Wq"], p["bq"], p["Wk"],
+                               p["bk"], p["Wv"], p["bv"], heads)
+
+    fu = fuse(torch.stack(uv, 1), P["fuse_u"], batch.get("drop_u"))
+    fi = fuse(torch.stack(iv, 1), P["fuse_i"], batch.get("drop_i"))
+    # ---- head (model.py:156-173)
+    seq = torch.as_tensor(batch["sequence"], dtype=torch.long)
+    m = torch.as_tensor(batch["mask"], dtype=fu.dtype)[:, None, :]
+    sb = torch_layer_norm_td(m @ fi[seq], *P["ln"][0]) + torch_layer_norm_td(
+        m @ P["posEmbed"][None].expand(seq.shape[0], -1, -1), *P["ln"][1])
+    att = sb
+    for i, p in enumerate(P["att"]):
+        a1 = torch_mhsa_mean(torch_layer_norm_td(att, *P["ln"][2 + i]), p["Wq"], p["bq"], p["Wk"], p["bk"],
+                             p["Wv"], p["bv"], heads)[:, None, :]
+        att = lk(a1) + att
+    att_user = att.sum(1)
+    uids = torch.as_tensor(batch["uids"], dtype=torch.long)
+    iids = torch.as_tensor(batch["iids"], dtype=torch.long)
+    ulocs = torch.as_tensor(batch["uLocs_seq"], dtype=torch.long)
+    preds = (fu[uids] * fi[iids]).sum(-1) + (lk(att_user[ulocs]) * fi[iids]).sum(-1)
+    n = preds.shape[0] // 2
+    pre_loss = torch.clamp(1.0 - (preds[:n] - preds[n:]), min=0).mean()
+    # ---- SSL (model.py:174-205)
+    ssl = 0.0
+    for k in range(T):
+        su = torch.as_tensor(batch["suids"][k], dtype=torch.long)
+        si = torch.as_tensor(batch["siids"][k], dtype=torch.long)
+        meta1 = torch.cat([fu * uv[k], fu, uv[k]], dim=-1)
+        meta2 = lk(meta1 @ P["meta2_W"] + P["meta2_b"])
+        w = torch.sigmoid(meta2 @ P["meta3_W"] + P["meta3_b"]).squeeze(-1)[su]
+        ns = su.shape[0] // 2
+        s_final = lk(fu[su] * fi[si]).sum(-1).detach()
+        S = w[:ns] * s_final[:ns] - w[ns:] * s_final[ns:]
+        p1 = lk(uv[k][su] * iv[k][si]).sum(-1)
+        ssl = ssl + torch.clamp(1.0 - S * (p1[:ns] - p1[ns:]), min=0).sum()
+    return pre_loss, ssl, fu, fi

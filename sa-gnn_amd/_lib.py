@@ -73,6 +73,23 @@ SIGNATURES = {
     "sagnn_leaky_add_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     "sagnn_pair_score_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                      c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_void_p]),
+    "sagnn_pair_score_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                         c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_int64, c_int, c_void_p]),
+    "sagnn_prod_leaky_sum_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p,
+                                         c_int64, c_int, c_void_p]),
+    "sagnn_prod_leaky_sum_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_float,
+                                             c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "sagnn_meta_features_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int,
+                                        c_void_p]),
+    "sagnn_meta_features_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_int64, c_int, c_void_p]),
+    "sagnn_leaky_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_void_p]),
+    "sagnn_rowdot_sigmoid_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "sagnn_rowdot_sigmoid_bwd_f32": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                             c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "sagnn_hinge_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "sagnn_mul_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "sagnn_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                     c_float, c_float, c_int64, c_void_p]),

@@ -143,3 +143,241 @@ def interval_fusion(x, p: dict, heads: int, drop_scale=None):
     """Differentiable interval fusion; p as in ops.interval_fusion."""
     return IntervalFusionFn.apply(x, p["lstm_W"], p["lstm_b"], p["ln_gamma"], p["ln_beta"], p["Wq"], p["bq"],
                                   p["Wk"], p["bk"], p["Wv"], p["bv"], heads, drop_scale)
+
+
+# ----------------------------------------------------------------------------------------------
+# Stand-alone differentiable pieces (prediction head, SSL branch): model.py:156-205, 241-250
+# ----------------------------------------------------------------------------------------------
+
+
+def _mhsa_mean_backward(y, Wq, bq, Wk, bk, Wv, bv, heads, g_out):
+    """y [n, t, d] dense, g_out [n, d] -> (dy [n, t, d], dWq, dbq, dWk, dbk, dWv, dbv)."""
+    lib = ops._lib.load()
+    n, t, d = y.shape
+    dev = y.device
+    Wqkv = torch.cat([Wq, Wk, Wv], dim=1).detach().contiguous()
+    bqkv = torch.cat([bq, bk, bv]).detach().contiguous()
+    y2 = y.reshape(n * t, d)
+    qkv = ops.dense_nn(y2, Wqkv, bqkv)
+    ops.check(lib.sagnn_attn_bwd_f32(qkv.data_ptr(), g_out.data_ptr(), d, n, t, d, heads, ops._stream()))
+    dWqkv = torch.zeros((d, 3 * d), dtype=torch.float32, device=dev)
+    dbqkv = torch.zeros(3 * d, dtype=torch.float32, device=dev)
+    ops.dense_tn(y2, qkv, dWqkv, dbqkv)
+    dy = ops.dense_nn(qkv, Wqkv.t().contiguous(), None).view(n, t, d)
+    dWs = [dWqkv[:, i * d:(i + 1) * d].contiguous() for i in range(3)]
+    dbs = [dbqkv[i * d:(i + 1) * d].contiguous() for i in range(3)]
+    return dy, dWs[0], dbs[0], dWs[1], dbs[1], dWs[2], dbs[2]
+
+
+class SpmmFn(torch.autograd.Function):
+    """y = A·x (pattern sum, no activation): the masked sums of model.py:161-162 on a per-batch
+    CSR. Backward is the same kernel on the transposed CSR."""
+
+    @staticmethod
+    def forward(ctx, x, plan, plan_t):
+        ctx.plan_t = plan_t
+        return ops.spmm(plan, x.detach().contiguous(), 1.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.spmm(ctx.plan_t, g.contiguous(), 1.0), None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        x = x.detach().contiguous()
+        ctx.save_for_backward(x, gamma)
+        return ops.layernorm_td(x, gamma.detach(), beta.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma = ctx.saved_tensors
+        n, t, d = x.shape
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        dgamma = torch.zeros(d, dtype=torch.float32, device=x.device)
+        dbeta = torch.zeros(d, dtype=torch.float32, device=x.device)
+        ops.check(ops._lib.load().sagnn_layernorm_td_bwd_f32(
+            x.data_ptr(), t * d, g.data_ptr(), t * d, n, t, d, ops._vec("gamma", gamma.detach(), d), 1e-12,
+            dx.data_ptr(), t * d, dgamma.data_ptr(), dbeta.data_ptr(), ops._stream()))
+        return dx, dgamma, dbeta
+
+
+class MhsaMeanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Wq, bq, Wk, bk, Wv, bv, heads):
+        x = x.detach().contiguous()
+        ctx.save_for_backward(x, Wq, bq, Wk, bk, Wv, bv)
+        ctx.heads = heads
+        return ops.mhsa_mean(x, Wq.detach(), bq.detach(), Wk.detach(), bk.detach(), Wv.detach(), bv.detach(), heads)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Wq, bq, Wk, bk, Wv, bv = ctx.saved_tensors
+        return _mhsa_mean_backward(x, Wq, bq, Wk, bk, Wv, bv, ctx.heads, g.contiguous()) + (None,)
+
+
+class LeakyAddFn(torch.autograd.Function):
+    """out = max(leaky*a, a) + b (model.py:166)."""
+
+    @staticmethod
+    def forward(ctx, a, b, leaky):
+        a = a.detach().contiguous()
+        ctx.save_for_backward(a)
+        ctx.leaky = leaky
+        return ops.leaky_add(a, b.detach().contiguous(), leaky)
+
+    @staticmethod
+    def backward(ctx, g):
+        (a,) = ctx.saved_tensors
+        g = g.contiguous()
+        da = torch.empty_like(a)
+        ops.check(ops._lib.load().sagnn_leaky_f32(a.data_ptr(), g.data_ptr(), da.data_ptr(), ctx.leaky, a.numel(), 1,
+                                                  ops._stream()))
+        return da, g, None
+
+
+class PairScoreFn(torch.autograd.Function):
+    """preds[e] = <U[u], I[i]> + <leaky(S[l]), I[i]> (model.py:169-173; iEmbed_att IS final_item_vector)."""
+
+    @staticmethod
+    def forward(ctx, U, I, S, uids, iids, locs, leaky):
+        U, I, S = U.detach().contiguous(), I.detach().contiguous(), S.detach().contiguous()
+        ctx.save_for_backward(U, I, S, uids, iids, locs)
+        ctx.leaky = leaky
+        return ops.pair_score(U, I, uids, iids, S=S, A=I, locs=locs, leaky=leaky)
+
+    @staticmethod
+    def backward(ctx, g):
+        U, I, S, uids, iids, locs = ctx.saved_tensors
+        d = U.shape[1]
+        dU, dI, dS = torch.zeros_like(U), torch.zeros_like(I), torch.zeros_like(S)
+        g = g.contiguous()
+        ops.check(ops._lib.load().sagnn_pair_score_bwd_f32(
+            U.data_ptr(), d, I.data_ptr(), d, S.data_ptr(), d, I.data_ptr(), d, uids.data_ptr(), iids.data_ptr(),
+            locs.data_ptr(), ctx.leaky, g.data_ptr(), dU.data_ptr(), dI.data_ptr(), dS.data_ptr(), dI.data_ptr(),
+            uids.numel(), d, ops._stream()))
+        return dU, dI, dS, None, None, None, None
+
+
+class ProdLeakySumFn(torch.autograd.Function):
+    """s[e] = sum_j leaky(X[u][j] * Y[i][j]) (model.py:191, :199)."""
+
+    @staticmethod
+    def forward(ctx, X, Y, uids, iids, leaky):
+        X, Y = X.detach().contiguous(), Y.detach().contiguous()
+        ctx.save_for_backward(X, Y, uids, iids)
+        ctx.leaky = leaky
+        d = X.shape[1]
+        out = torch.empty(uids.numel(), dtype=torch.float32, device=X.device)
+        ops.check(ops._lib.load().sagnn_prod_leaky_sum_f32(X.data_ptr(), d, Y.data_ptr(), d, uids.data_ptr(),
+                                                           iids.data_ptr(), leaky, out.data_ptr(), uids.numel(), d,
+                                                           ops._stream()))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        X, Y, uids, iids = ctx.saved_tensors
+        d = X.shape[1]
+        dX, dY = torch.zeros_like(X), torch.zeros_like(Y)
+        g = g.contiguous()
+        ops.check(ops._lib.load().sagnn_prod_leaky_sum_bwd_f32(X.data_ptr(), d, Y.data_ptr(), d, uids.data_ptr(),
+                                                               iids.data_ptr(), ctx.leaky, g.data_ptr(), dX.data_ptr(),
+                                                               dY.data_ptr(), uids.numel(), d, ops._stream()))
+        return dX, dY, None, None, None
+
+
+def _pad_cols(W, kp):
+    out = torch.zeros(W.shape[:-1] + (kp,), dtype=W.dtype, device=W.device)
+    out[..., : W.shape[-1]] = W
+    return out
+
+
+class MetaWeightFn(torch.autograd.Function):
+    """w[e] = sigmoid(FC(leaky(FC([F*V | F | V][u_e])))) (model.py:179-182), evaluated for the sampled
+    users only (the reference computes it for every user and gathers afterwards: same values).
+    W2 [3d, k], b2 [k], W3 [k, 1], b3 [1]; k = ssldim is padded to a multiple of 32 for the MFMA
+    product."""
+
+    @staticmethod
+    def forward(ctx, F, V, uids, W2, b2, W3, b3, leaky):
+        lib = ops._lib.load()
+        F, V = F.detach().contiguous(), V.detach().contiguous()
+        n, d, k = uids.numel(), F.shape[1], W2.shape[1]
+        kp = (k + 31) // 32 * 32
+        dev = F.device
+        m1 = torch.empty((n, 3 * d), dtype=torch.float32, device=dev)
+        ops.check(lib.sagnn_meta_features_f32(F.data_ptr(), d, V.data_ptr(), d, uids.data_ptr(), m1.data_ptr(), n, d,
+                                              ops._stream()))
+        W2p = _pad_cols(W2.detach(), kp).contiguous()
+        z1 = ops.dense_nn(m1, W2p, _pad_cols(b2.detach(), kp).contiguous())
+        a1 = torch.empty_like(z1)
+        ops.check(lib.sagnn_leaky_f32(z1.data_ptr(), None, a1.data_ptr(), leaky, z1.numel(), 0, ops._stream()))
+        w = torch.empty(n, dtype=torch.float32, device=dev)
+        w3 = W3.detach().reshape(-1).contiguous()
+        ops.check(lib.sagnn_rowdot_sigmoid_f32(a1.data_ptr(), kp, w3.data_ptr(), b3.detach().data_ptr(), w.data_ptr(),
+                                               n, k, ops._stream()))
+        ctx.save_for_backward(F, V, uids, m1, z1, a1, w, W2p, w3)
+        ctx.cfg = (leaky, k, kp)
+        return w
+
+    @staticmethod
+    def backward(ctx, dw):
+        lib = ops._lib.load()
+        F, V, uids, m1, z1, a1, w, W2p, w3 = ctx.saved_tensors
+        leaky, k, kp = ctx.cfg
+        n, d = uids.numel(), F.shape[1]
+        dev = F.device
+        dw = dw.contiguous()
+        dA = torch.zeros_like(a1)
+        dw3 = torch.zeros(k, dtype=torch.float32, device=dev)
+        db3 = torch.zeros(1, dtype=torch.float32, device=dev)
+        ops.check(lib.sagnn_rowdot_sigmoid_bwd_f32(a1.data_ptr(), kp, w3.data_ptr(), w.data_ptr(), dw.data_ptr(),
+                                                   dA.data_ptr(), kp, dw3.data_ptr(), db3.data_ptr(), n, k,
+                                                   ops._stream()))
+        dz1 = torch.empty_like(z1)
+        ops.check(lib.sagnn_leaky_f32(z1.data_ptr(), dA.data_ptr(), dz1.data_ptr(), leaky, z1.numel(), 1, ops._stream()))
+        dW2p = torch.zeros((3 * d, kp), dtype=torch.float32, device=dev)
+        db2p = torch.zeros(kp, dtype=torch.float32, device=dev)
+        ops.dense_tn(m1, dz1, dW2p, db2p)
+        dm1 = ops.dense_nn(dz1, W2p.t().contiguous(), None)
+        dF, dV = torch.zeros_like(F), torch.zeros_like(V)
+        ops.check(lib.sagnn_meta_features_bwd_f32(F.data_ptr(), d, V.data_ptr(), d, uids.data_ptr(), dm1.data_ptr(),
+                                                  dF.data_ptr(), dV.data_ptr(), n, d, ops._stream()))
+        return dF, dV, None, dW2p[:, :k].contiguous(), db2p[:k].contiguous(), dw3.view(k, 1), db3, None
+
+
+class HingeFn(torch.autograd.Function):
+    """scale * sum max(0, 1 - S*(pos - neg)), S = wp*sp - wn*sn or 1 (model.py:202, :244). sp/sn are
+    constants (tf.stop_gradient, model.py:192-193)."""
+
+    @staticmethod
+    def forward(ctx, pos, neg, wp, wn, sp, sn, scale):
+        lib = ops._lib.load()
+        pos, neg = pos.detach().contiguous(), neg.detach().contiguous()
+        n = pos.numel()
+        dev = pos.device
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        dpos, dneg = torch.empty_like(pos), torch.empty_like(neg)
+        weighted = wp is not None
+        if weighted:
+            wp, wn = wp.detach().contiguous(), wn.detach().contiguous()
+            sp, sn = sp.detach().contiguous(), sn.detach().contiguous()
+            dwp, dwn = torch.empty_like(wp), torch.empty_like(wn)
+        ops.check(lib.sagnn_hinge_f32(pos.data_ptr(), neg.data_ptr(), ops._ptr(wp) if weighted else None,
+                                      ops._ptr(wn) if weighted else None, ops._ptr(sp) if weighted else None,
+                                      ops._ptr(sn) if weighted else None, float(scale), loss.data_ptr(),
+                                      dpos.data_ptr(), dneg.data_ptr(), dwp.data_ptr() if weighted else None,
+                                      dwn.data_ptr() if weighted else None, n, ops._stream()))
+        ctx.weighted = weighted
+        ctx.save_for_backward(dpos, dneg, *((dwp, dwn) if weighted else ()))
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        dpos, dneg = saved[0] * g, saved[1] * g
+        if ctx.weighted:
+            return dpos, dneg, saved[2] * g, saved[3] * g, None, None, None
+        return dpos, dneg, None, None, None, None, None

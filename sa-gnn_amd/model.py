@@ -14,6 +14,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from . import autograd as ag
 from . import ops
 from .Params import args
 from .Utils import NNLayers as NNs
@@ -131,7 +132,18 @@ class Recommender:
             NNs.defineRandomNameParam([d, d], reg=True)
         self._define_fusion_params()
         self._define_head_params()
+        self._define_ssl_params()
         return self.forward()
+
+    def _define_ssl_params(self):
+        """The SSL meta-net (model.py:179-182): FC(3d -> ssldim, bias, leakyRelu, reg) named 'meta2'
+        and FC(ssldim -> 1, bias, sigmoid, reg) named 'meta3', shared by all intervals; biases are
+        zeros and not L2-regularised (Utils/NNLayers.py:117-124)."""
+        d = args.latdim
+        self.meta2_W = NNs.defineParam("meta2", [3 * d, args.ssldim], reg=True)
+        self.meta2_b = NNs.defineParam("meta2Bias", [args.ssldim], initializer="zeros")
+        self.meta3_W = NNs.defineParam("meta3", [args.ssldim, 1], reg=True)
+        self.meta3_b = NNs.defineParam("meta3Bias", [1], initializer="zeros")
 
     def _define_head_params(self):
         """Variables of the prediction head in the reference's creation order (model.py:158-166):
@@ -273,6 +285,199 @@ class Recommender:
         return {"HR": tot[0] / num, "NDCG": tot[1] / num, "HR5": tot[2] / num, "NDCG5": tot[3] / num,
                 "HR20": tot[4] / num, "NDCG20": tot[5] / num}
 
+    # ------------------------------------------------------------------ training
+    def _i32(self, v):
+        return torch.as_tensor(np.asarray(v, dtype=np.int32), device=self.device)
+
+    def train_loss(self, batch, keep_rate=None):
+        """The reference's loss for one step (model.py:104-205, 241-246) as a torch autograd graph
+        whose nodes are HIP operators (sa_gnn_amd.autograd). batch: dict with uids, iids,
+        uLocs_seq, sequence [args.batch, pos_length], mask, suids[k], siids[k]. Returns
+        (preLoss, sslloss) as 1-element tensors; total loss = preLoss + ssl_reg*sslloss (+ the L2
+        term, applied inside the optimiser step)."""
+        T, L, d, heads, leaky = args.graphNum, args.gnn_layer, args.latdim, args.num_attention_heads, NNs.leaky
+        keep = args.keepRate if keep_rate is None else keep_rate
+        uv, iv = [], []
+        for k in range(T):
+            u, i = ag.gnn_interval(self.uEmbed[k], self.iEmbed[k], self.subAdj[k].plan, self.subTpAdj[k].plan, L, leaky)
+            uv.append(u)
+            iv.append(i)
+        finals = []
+        for xs, (gamma, beta), att, key in ((uv, self.ln[0], self.multihead_self_attention0, "drop_u"),
+                                            (iv, self.ln[1], self.multihead_self_attention1, "drop_i")):
+            x = torch.stack(xs, 0).permute(1, 0, 2)                       # [N, T, d] view of [T, N, d]
+            drop = batch.get(key)
+            if drop is None and keep < 1.0:                               # DropoutWrapper(output_keep_prob)
+                drop = (torch.rand((x.shape[0], T, d), device=self.device) < keep).float() / keep
+            p = {"lstm_W": self.lstm_kernel, "lstm_b": self.lstm_bias, "ln_gamma": gamma, "ln_beta": beta}
+            p.update(att.weights())
+            finals.append(ag.interval_fusion(x, p, heads, drop_scale=drop))
+        fu, fi = finals
+        # ---- head (model.py:156-173)
+        pi, pp = self._masked_sum_plans(batch["sequence"], batch["mask"])
+        pit, ppt = self._masked_sum_plans_t(batch["sequence"], batch["mask"])
+        seq_tok = ag.SpmmFn.apply(fi, pi, pit)
+        pos_tok = ag.SpmmFn.apply(self.posEmbed, pp, ppt)
+        B = seq_tok.shape[0]
+        ln = lambda x, gb: ag.LayerNormFn.apply(x.view(B, 1, d), gb[0], gb[1]).view(B, d)
+        zero = torch.zeros((B, d), dtype=torch.float32, device=self.device)
+        att = ag.LeakyAddFn.apply(ln(seq_tok, self.head_ln[0]), ln(pos_tok, self.head_ln[1]), 1.0)
+        for i, mh in enumerate(self.multihead_self_attention_sequence):
+            w = mh.weights()
+            a1 = ag.MhsaMeanFn.apply(ln(att, self.head_ln[2 + i]).view(B, 1, d), w["Wq"], w["bq"], w["Wk"], w["bk"],
+                                     w["Wv"], w["bv"], heads)
+            att = ag.LeakyAddFn.apply(a1, att, leaky)
+        del zero
+        preds = ag.PairScoreFn.apply(fu, fi, att, self._i32(batch["uids"]), self._i32(batch["iids"]),
+                                     self._i32(batch["uLocs_seq"]), leaky)
+        n = preds.shape[0] // 2
+        pre_loss = ag.HingeFn.apply(preds[:n], preds[n:], None, None, None, None, 1.0 / max(n, 1))
+        # ---- SSL (model.py:174-205)
+        ssl = torch.zeros(1, dtype=torch.float32, device=self.device)
+        for k in range(T):
+            su, si = self._i32(batch["suids"][k]), self._i32(batch["siids"][k])
+            ns = su.numel() // 2
+            if ns == 0:
+                continue
+            w = ag.MetaWeightFn.apply(fu, uv[k], su, self.meta2_W, self.meta2_b, self.meta3_W, self.meta3_b, leaky)
+            s_final = ag.ProdLeakySumFn.apply(fu.detach(), fi.detach(), su, si, leaky)      # stop_gradient
+            p1 = ag.ProdLeakySumFn.apply(uv[k], iv[k], su, si, leaky)
+            ssl = ssl + ag.HingeFn.apply(p1[:ns], p1[ns:], w[:ns], w[ns:], s_final[:ns], s_final[ns:], 1.0)
+        return pre_loss, ssl
+
+    def _masked_sum_plans_t(self, sequence, mask):
+        """Transposed per-batch CSRs (rows = items / positions, columns = batch slots) for the
+        backward of the masked sums."""
+        sequence = np.asarray(sequence, dtype=np.int64)
+        keep = np.asarray(mask) != 0
+        B, L = keep.shape
+        slots = np.broadcast_to(np.arange(B, dtype=np.int32)[:, None], (B, L))[keep]
+        out = []
+        for rows, n_rows in ((sequence[keep], args.item), (np.broadcast_to(np.arange(L), (B, L))[keep], L)):
+            order = np.argsort(rows, kind="stable")
+            rowptr = np.zeros(n_rows + 1, dtype=np.int32)
+            np.cumsum(np.bincount(rows, minlength=n_rows), out=rowptr[1:])
+            out.append(ops.SpmmPlan(rowptr, np.ascontiguousarray(slots[order]), n_rows, B, device=self.device,
+                                    validate=False))
+        return out
+
+    def sampleTrainBatch(self, batIds, labelMat, timeMat=None, train_sample_num=40):
+        """reference model.py:252-302: per user one positive (one of the last pred_num+1 items before
+        the held-out one, repeated sampNum times) against sampNum random negatives; the sequence
+        fed to the head stops before the chosen positive."""
+        from .DataHandler import negSamp
+        from random import randint
+        temTst = self.handler.tstInt[batIds]
+        temLabel = labelMat[batIds].toarray()
+        batch = len(batIds)
+        half_u, half_i, half_l, neg_i = [], [], [], []
+        sequence = np.zeros((args.batch, args.pos_length), dtype=np.int64)
+        mask = np.zeros((args.batch, args.pos_length), dtype=np.float32)
+        for i in range(batch):
+            u = int(batIds[i])
+            posset = self.handler.sequence[u][:-1]
+            sampNum = min(train_sample_num, len(posset))
+            choose = 1
+            if sampNum == 0:
+                poslocs = [np.random.choice(args.item)]
+                neglocs = [poslocs[0]]
+            else:
+                choose = randint(1, max(min(args.pred_num + 1, len(posset) - 3), 1))
+                poslocs = [posset[-choose]] * sampNum
+                neglocs = negSamp(temLabel[i], sampNum, args.item, [self.handler.sequence[u][-1], temTst[i]],
+                                  self.handler.item_with_pop)
+            for j in range(sampNum):
+                half_u.append(u)
+                half_l.append(i)
+                half_i.append(int(poslocs[j]))
+                neg_i.append(int(neglocs[j]))
+            posset = posset[:-choose]
+            if len(posset) == 0:
+                continue
+            if len(posset) <= args.pos_length:
+                sequence[i, -len(posset):] = posset
+                mask[i, -len(posset):] = 1
+            else:
+                sequence[i] = posset[-args.pos_length:]
+                mask[i] = 1
+        return half_u + half_u, half_i + neg_i, sequence, mask, half_l + half_l
+
+    def sampleSslBatch(self, batIds, labelMat, use_epsilon=True):
+        """reference model.py:304-339: per interval and user up to sslNum (item, item) pairs drawn
+        with replacement from the user's items of that interval, written INTERLEAVED
+        (pair j at 2j, 2j+1) — the loss later splits the vector by halves (model.py:192-201)."""
+        uLocs, iLocs, uLocs_seq = [], [], []
+        for k in range(args.graphNum):
+            lab = labelMat[k][batIds].toarray()
+            us, its, ls = [], [], []
+            for i in range(len(batIds)):
+                posset = np.reshape(np.argwhere(lab[i] != 0), [-1])
+                sslNum = min(args.sslNum, len(posset) // 2)
+                if sslNum == 0:
+                    continue                                   # the reference's range(0) writes nothing
+                picks = np.random.choice(posset, sslNum * 2)
+                for j in range(sslNum):
+                    us += [int(batIds[i])] * 2
+                    ls += [i] * 2
+                    its += [int(picks[j]), int(picks[sslNum + j])]
+            uLocs.append(us)
+            iLocs.append(its)
+            uLocs_seq.append(ls)
+        return uLocs, iLocs, uLocs_seq
+
+    def _trainable(self):
+        return {k: v for k, v in NNs.params.items() if v.requires_grad}
+
+    def trainEpoch(self):
+        """reference model.py:341-382: trnNum users per epoch in batches of args.batch."""
+        if getattr(self, "optimizer", None) is None:
+            self.optimizer = ops.Adam(self._trainable(), lr=args.lr, decay=args.decay, decay_step=args.decay_step,
+                                      reg=args.reg, reg_names=set(NNs.regParams))
+        sfIds = np.random.permutation(args.user)[:args.trnNum]
+        steps = int(np.ceil(len(sfIds) / args.batch))
+        epochLoss = epochPreLoss = 0.0
+        for i in range(steps):
+            batIds = sfIds[i * args.batch:(i + 1) * args.batch]
+            uLocs, iLocs, sequence, mask, uLocs_seq = self.sampleTrainBatch(batIds, self.handler.trnMat,
+                                                                            self.handler.timeMat, 40)
+            suLocs, siLocs, _ = self.sampleSslBatch(batIds, self.handler.subMat, False)
+            batch = {"uids": uLocs, "iids": iLocs, "uLocs_seq": uLocs_seq, "sequence": sequence, "mask": mask,
+                     "suids": suLocs, "siids": siLocs}
+            params = self._trainable()
+            for p in params.values():
+                p.grad = None
+            pre, ssl = self.train_loss(batch)
+            (pre + args.ssl_reg * ssl).backward()
+            reg = float(args.reg * NNs.Regularize()) + float(args.ssl_reg * ssl)
+            self.optimizer.step({k: p.grad for k, p in params.items()})
+            epochPreLoss += float(pre)
+            epochLoss += float(pre) + reg
+        return {"Loss": epochLoss / steps, "preLoss": epochPreLoss / steps}
+
+    def saveHistory(self, directory="."):
+        """reference model.py:512-520: metric history + variables (torch.save instead of a TF
+        checkpoint; same file stems History/<save_path>.his and Models/<save_path>)."""
+        import os
+        import pickle
+        if args.epoch == 0:
+            return
+        os.makedirs(os.path.join(directory, "History"), exist_ok=True)
+        os.makedirs(os.path.join(directory, "Models"), exist_ok=True)
+        with open(os.path.join(directory, "History", args.save_path + ".his"), "wb") as fs:
+            pickle.dump(self.metrics, fs)
+        torch.save({k: v.detach().cpu() for k, v in NNs.params.items()}, os.path.join(directory, "Models", args.save_path))
+
+    def loadModel(self, directory="."):
+        """reference model.py:522-526."""
+        import os
+        import pickle
+        state = torch.load(os.path.join(directory, "Models", args.load_model), weights_only=True)
+        with torch.no_grad():
+            for k, v in state.items():
+                NNs.params[k].copy_(v)
+        with open(os.path.join(directory, "History", args.load_model + ".his"), "rb") as fs:
+            self.metrics = pickle.load(fs)
+
     # ------------------------------------------------------------------ model construction
     def prepareModel(self):
         """reference model.py:207-240 up to the call of ours(): adjacency constants for every
@@ -290,6 +495,34 @@ class Recommender:
         self._scratch_u = self._scratch_i = None
         self.final_user_vector, self.final_item_vector = self.ours()
 
+    def makePrint(self, name, ep, reses, save):
+        ret = "Epoch %d/%d, %s: " % (ep, args.epoch, name)
+        for metric, val in reses.items():
+            ret += "%s = %.4f, " % (metric, val)
+            tem = name + metric
+            if save and tem in self.metrics:
+                self.metrics[tem].append(val)
+        return ret[:-2] + "  "
+
     def run(self):
+        """reference model.py:41-70: train args.epoch epochs, test every tstEpoch, keep the best NDCG."""
         self.prepareModel()
-        return self.final_user_vector, self.final_item_vector
+        if args.load_model is not None:
+            self.loadModel()
+            stloc = len(self.metrics["TrainLoss"]) * args.tstEpoch - (args.tstEpoch - 1)
+        else:
+            stloc = 0
+        maxndcg, maxres, maxepoch = 0.0, dict(), 0
+        for ep in range(stloc, args.epoch):
+            test = ep % args.tstEpoch == 0
+            print(self.makePrint("Train", ep, self.trainEpoch(), test))
+            if test:
+                reses = self.testEpoch()
+                print(self.makePrint("Test", ep, reses, test))
+                if reses["NDCG"] > maxndcg:
+                    self.saveHistory()
+                    maxndcg, maxres, maxepoch = reses["NDCG"], reses, ep
+        reses = self.testEpoch()
+        print(self.makePrint("Test", args.epoch, reses, True))
+        print(self.makePrint("max", maxepoch, maxres, True))
+        return reses

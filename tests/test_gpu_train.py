@@ -1,0 +1,133 @@
+"""GPU parity of the full training objective: loss values and the gradient of
+every trainable tensor of the model against float64 torch.autograd over the oracle's restatement
+of model.py:104-205, 241-246, on a batch drawn by the package's own samplers."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import selfgnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, d, ssldim, att_layer):
+    from sa_gnn_amd import synthetic
+    from sa_gnn_amd.DataHandler import DataHandler
+    from sa_gnn_amd.Params import args
+    from sa_gnn_amd.Utils import NNLayers as NNs
+    from sa_gnn_amd.model import Recommender
+    rng = np.random.default_rng(31)
+    args.graphNum, args.gnn_layer, args.latdim, args.leaky, args.ssldim = 2, 2, d, 0.5, ssldim
+    args.att_layer, args.batch, args.pos_length, args.testSize, args.test = att_layer, 16, 12, 20, True
+    args.sslNum, args.pred_num, args.keepRate, args.ssl_reg, args.reg = 3, 2, 1.0, 0.5, 1e-2
+    U, I = 70, 60
+    tmt = synthetic.make_trn_mat_time(U, I, [700, 650])
+    seq = synthetic.make_sequence(tmt)
+    tst_int = [int(rng.integers(0, I)) if u % 2 else None for u in range(U)]
+    handler = DataHandler.from_memory(tmt, seq, tst_int, {u + 1: list(rng.integers(1, I + 1, size=30)) for u in range(U)})
+    rec = Recommender(dev, handler)
+    rec.prepareModel()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    with torch.no_grad():
+        for name in list(NNs.params):
+            if name.endswith("bias") or name.endswith("beta") or name.endswith("Bias"):
+                NNs.params[name].copy_(0.1 * torch.randn(NNs.params[name].shape, generator=g))
+        for k in ("uEmbed", "iEmbed", "posEmbed"):
+            NNs.params[k].mul_(20)
+    return rec, handler, NNs, args
+
+
+def _oracle_params(rec, NNs):
+    t64 = lambda v: v.detach().cpu().double().requires_grad_(True)
+    leaves = {}
+
+    def leaf(name):
+        if name not in leaves:
+            leaves[name] = t64(NNs.params[name])
+        return leaves[name]
+
+    def mh(att):
+        inv = {id(v): k for k, v in NNs.params.items()}
+        return {k: leaf(inv[id(v)]) for k, v in att.weights().items()}
+
+    inv = {id(v): k for k, v in NNs.params.items()}
+    P = {"uEmbed": leaf("uEmbed"), "iEmbed": leaf("iEmbed"), "posEmbed": leaf("posEmbed"),
+         "meta2_W": leaf("meta2"), "meta2_b": leaf("meta2Bias"), "meta3_W": leaf("meta3"), "meta3_b": leaf("meta3Bias")}
+    for key, (gm, bt), att in (("fuse_u", rec.ln[0], rec.multihead_self_attention0),
+                                ("fuse_i", rec.ln[1], rec.multihead_self_attention1)):
+        p = {"lstm_W": leaf("rnn_lstm_kernel"), "lstm_b": leaf("rnn_lstm_bias"), "ln_gamma": leaf(inv[id(gm)]),
+             "ln_beta": leaf(inv[id(bt)])}
+        p.update(mh(att))
+        P[key] = p
+    P["ln"] = [(leaf(inv[id(gm)]), leaf(inv[id(bt)])) for gm, bt in rec.head_ln]
+    P["att"] = [mh(a) for a in rec.multihead_self_attention_sequence]
+    return P, leaves
+
+
+@pytest.mark.parametrize("d,ssldim,att_layer,dropout", [(64, 48, 2, False), (32, 32, 1, True)])
+def test_training_objective_gradients(dev, d, ssldim, att_layer, dropout):
+    rec, handler, NNs, args = _setup(dev, d, ssldim, att_layer)
+    np.random.seed(3)
+    import random
+    random.seed(3)
+    batIds = np.random.permutation(args.user)[:args.batch]
+    uL, iL, sequence, mask, uLs = rec.sampleTrainBatch(batIds, handler.trnMat, handler.timeMat, 5)
+    su, si, _ = rec.sampleSslBatch(batIds, handler.subMat, False)
+    assert len(uL) == len(iL) == len(uLs) and len(uL) % 2 == 0 and all(len(a) % 2 == 0 for a in su)
+    batch = {"uids": uL, "iids": iL, "uLocs_seq": uLs, "sequence": sequence, "mask": mask, "suids": su, "siids": si}
+    obatch = dict(batch)
+    if dropout:
+        g = torch.Generator(device="cpu").manual_seed(4)
+        for key, n in (("drop_u", args.user), ("drop_i", args.item)):
+            m = (torch.rand((n, args.graphNum, d), generator=g) < 0.5).float() * 2.0
+            batch[key] = m.to(dev)
+            obatch[key] = m.double()
+    # HIP path
+    for p in NNs.params.values():
+        p.grad = None
+    pre, ssl = rec.train_loss(batch, keep_rate=1.0)
+    (pre + args.ssl_reg * ssl).backward()
+    # oracle
+    P, leaves = _oracle_params(rec, NNs)
+    adj = [O.trans_to_lsts(m)[0] for m in handler.subMat]
+    tp = [O.trans_to_lsts(O.transpose(m))[0] for m in handler.subMat]
+    opre, ossl, _, _ = O.torch_train_loss(P, adj, tp, obatch, {"T": 2, "L": 2, "leaky": 0.5, "heads": 16})
+    (opre + args.ssl_reg * ossl).backward()
+    assert abs(float(pre) - float(opre)) <= 1e-4 * max(abs(float(opre)), 1.0)
+    assert abs(float(ssl) - float(ossl)) <= 1e-4 * max(abs(float(ossl)), 1.0)
+    checked = 0
+    for name, leaf in leaves.items():
+        got = NNs.params[name].grad
+        want = leaf.grad
+        if want is None:
+            assert got is None or float(got.abs().max()) == 0.0, name
+            continue
+        assert got is not None, f"no gradient reached {name}"
+        a, b = got.cpu().double().numpy(), want.numpy()
+        floor = max(5e-5 * np.abs(b).max(), 2e-5)
+        if name.endswith("k_bias"):
+            # analytically ~0 (a key bias shifts every score of a row alike); what is left is the
+            # cancellation noise of terms as large as those of the key kernel's gradient
+            floor = max(floor, 1e-3 * float(leaves[name.replace("k_bias", "k_kernel")].grad.abs().max()))
+        tol = 2e-4 * np.abs(b) + floor
+        bad = np.abs(a - b) > tol
+        assert not bad.any(), f"{name}: {bad.sum()}/{bad.size} off, worst {np.abs(a - b)[bad].max():.3e} (scale {np.abs(b).max():.3e})"
+        checked += 1
+    assert checked >= 20
+    # the dead [d, d] weights of messagePropagate and timeEmbed get no gradient (L2 only)
+    assert NNs.params["timeEmbed"].grad is None
+
+
+def test_train_epoch_runs_and_improves_loss(dev):
+    """Two epochs of the reference's loop (samplers -> loss -> backward -> Adam) on a toy dataset:
+    finite losses, parameters move, preLoss goes down; then the evaluator runs on the result."""
+    rec, handler, NNs, args = _setup(dev, 64, 32, 1)
+    args.trnNum, args.lr, args.keepRate, args.ssl_reg, args.reg = 64, 5e-3, 0.5, 1e-3, 1e-4
+    args.decay_step = args.trnNum // args.batch
+    np.random.seed(0)
+    before = NNs.params["uEmbed"].detach().clone()
+    losses = [rec.trainEpoch()["preLoss"] for _ in range(4)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert float((NNs.params["uEmbed"].detach() - before).abs().max()) > 0
+    res = rec.testEpoch()
+    assert 0.0 <= res["HR"] <= 1.0 and 0.0 <= res["NDCG"] <= 1.0
