@@ -448,10 +448,11 @@ class Recommender:
                 p.grad = None
             pre, ssl = self.train_loss(batch)
             (pre + args.ssl_reg * ssl).backward()
-            reg = float(args.reg * NNs.Regularize()) + float(args.ssl_reg * ssl)
+            with torch.no_grad():
+                reg = float(args.reg * NNs.Regularize()) + float(args.ssl_reg * ssl)
             self.optimizer.step({k: p.grad for k, p in params.items()})
-            epochPreLoss += float(pre)
-            epochLoss += float(pre) + reg
+            epochPreLoss += float(pre.detach())
+            epochLoss += float(pre.detach()) + reg
         return {"Loss": epochLoss / steps, "preLoss": epochPreLoss / steps}
 
     def saveHistory(self, directory="."):

@@ -94,3 +94,24 @@ def make_sequence(trn_mat_time):
     rows, cols = rows[order], cols[order]
     bounds = np.searchsorted(rows, np.arange(n_users + 1))
     return [cols[bounds[u]:bounds[u + 1]].tolist() for u in range(n_users)]
+
+
+def write_dataset(directory: str, n_users: int, n_items: int, nnz_per_interval, test_size: int = 1000,
+                  seed0: int = 1000):
+    """Writes a dataset in the reference's on-disk format under `directory` (what
+    preprocess_to_trnmat.ipynb / preprocess_to_sequence.ipynb produce): `trn_mat_time`
+    ([trnMat, subMat[T], timeMat]), `sequence`, `tst_int` (held-out item per test user, None for
+    the others; every second user is a test user) and `test_dict` (1-indexed user -> test_size
+    1-indexed candidate items). Returns the in-memory objects too."""
+    import os
+    import pickle
+    os.makedirs(directory, exist_ok=True)
+    tmt = make_trn_mat_time(n_users, n_items, nnz_per_interval, seed0)
+    seq = make_sequence(tmt)
+    rng = np.random.default_rng(seed0 + 7)
+    tst_int = [int(rng.integers(0, n_items)) if u % 2 == 0 else None for u in range(n_users)]
+    test_dict = {u + 1: [int(v) for v in rng.integers(1, n_items + 1, size=test_size)] for u in range(n_users)}
+    for name, obj in (("trn_mat_time", tmt), ("sequence", seq), ("tst_int", tst_int), ("test_dict", test_dict)):
+        with open(os.path.join(directory, name), "wb") as fs:
+            pickle.dump(obj, fs)
+    return tmt, seq, tst_int, test_dict

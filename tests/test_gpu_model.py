@@ -26,7 +26,7 @@ def test_recommender_hot_path_vs_oracle(dev):
     assert sum(1 for k in NNs.regParams if k.startswith("defaultParamName")) == 2 * 4 * 2
     assert NNs.params["uEmbed"].shape == (4, U, 64) and NNs.params["timeEmbed"].shape == (2, 64)
     lim = np.sqrt(6.0 / (4 * U + 4 * 64))
-    assert float(NNs.params["uEmbed"].abs().max()) <= lim
+    assert float(NNs.params["uEmbed"].detach().abs().max()) <= lim
     # give the zero-initialised biases / beta non-trivial values, then recompute
     g = torch.Generator(device="cpu").manual_seed(1)
     with torch.no_grad():

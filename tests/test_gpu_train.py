@@ -93,8 +93,8 @@ def test_training_objective_gradients(dev, d, ssldim, att_layer, dropout):
     tp = [O.trans_to_lsts(O.transpose(m))[0] for m in handler.subMat]
     opre, ossl, _, _ = O.torch_train_loss(P, adj, tp, obatch, {"T": 2, "L": 2, "leaky": 0.5, "heads": 16})
     (opre + args.ssl_reg * ossl).backward()
-    assert abs(float(pre) - float(opre)) <= 1e-4 * max(abs(float(opre)), 1.0)
-    assert abs(float(ssl) - float(ossl)) <= 1e-4 * max(abs(float(ossl)), 1.0)
+    assert abs(float(pre.detach()) - float(opre.detach())) <= 1e-4 * max(abs(float(opre)), 1.0)
+    assert abs(float(ssl.detach()) - float(ossl.detach())) <= 1e-4 * max(abs(float(ossl)), 1.0)
     checked = 0
     for name, leaf in leaves.items():
         got = NNs.params[name].grad

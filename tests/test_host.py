@@ -164,3 +164,19 @@ def test_powerlaw_generator_properties():
     assert du.max() > 20 * du.mean() / 4 and di.max() > 30 * di.mean()      # heavy tails
     u2, i2 = synthetic.powerlaw_edges(20000, 10000, 200000, seed=1000)
     assert torch.equal(u, u2) and torch.equal(i, i2)     # deterministic in the seed
+
+
+def test_write_dataset_roundtrip(tmp_path):
+    """The on-disk writer emits what DataHandler.LoadData (the reference's loader contract) reads."""
+    from sa_gnn_amd import synthetic
+    from sa_gnn_amd.DataHandler import DataHandler
+    from sa_gnn_amd.Params import args
+    tmt, seq, tst, tdict = synthetic.write_dataset(str(tmp_path / "toy"), 120, 90, [500, 400], test_size=20)
+    args.data = "toy"
+    h = DataHandler(root=str(tmp_path))
+    h.LoadData()
+    args.data = "yelp"
+    assert (args.user, args.item) == (120, 90) and len(h.subMat) == 2
+    assert len(h.tstUsrs) == 60 and h.tstInt[0] == tst[0] and h.tstInt[1] is None
+    assert h.test_dict[1] == tdict[1] and min(min(v) for v in h.test_dict.values()) >= 1
+    assert h.sequence == seq
