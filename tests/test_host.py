@@ -180,3 +180,37 @@ def test_write_dataset_roundtrip(tmp_path):
     assert len(h.tstUsrs) == 60 and h.tstInt[0] == tst[0] and h.tstInt[1] is None
     assert h.test_dict[1] == tdict[1] and min(min(v) for v in h.test_dict.values()) >= 1
     assert h.sequence == seq
+
+
+def test_sampler_invariants():
+    """Vectorised samplers keep the reference's contracts (model.py:252-339): mirrored halves,
+    negatives never interacted with nor the last / test item, SSL pairs interleaved and drawn
+    from the user's items of that interval."""
+    from sa_gnn_amd import synthetic
+    from sa_gnn_amd.DataHandler import DataHandler
+    from sa_gnn_amd.Params import args
+    from sa_gnn_amd.model import Recommender
+    args.graphNum, args.batch, args.pos_length, args.sslNum, args.pred_num = 3, 64, 20, 5, 2
+    U, I = 300, 200
+    tmt = synthetic.make_trn_mat_time(U, I, [3000, 2500, 2000])
+    seq = synthetic.make_sequence(tmt)
+    tst = [(u * 7) % I if u % 2 else None for u in range(U)]
+    h = DataHandler.from_memory(tmt, seq, tst, None)
+    rec = Recommender.__new__(Recommender)
+    rec.handler = h
+    np.random.seed(0)
+    bat = np.random.permutation(U)[:64]
+    uL, iL, sq, mk, uLs = rec.sampleTrainBatch(bat, h.trnMat, None, 7)
+    n = len(uL) // 2
+    assert n > 0 and uL[:n] == uL[n:] and uLs[:n] == uLs[n:] and sq.shape == (64, 20)
+    for e in range(n):
+        u = uL[e]
+        assert iL[e] in seq[u][:-1]                                   # positive: an earlier item of the user
+        assert h.trnMat[u, iL[n + e]] == 0 and iL[n + e] != seq[u][-1] and iL[n + e] != tst[u]
+        assert bat[uLs[e]] == u
+    assert set(np.unique(mk)) <= {0.0, 1.0} and np.all((sq != 0) <= (mk != 0) + (sq == 0))
+    su, si, sl = rec.sampleSslBatch(bat, h.subMat)
+    for k in range(3):
+        assert len(su[k]) % 2 == 0 and su[k][0::2] == su[k][1::2]
+        for e in range(len(su[k])):
+            assert h.subMat[k][su[k][e], si[k][e]] != 0
