@@ -241,6 +241,16 @@ int sagnn_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, i
                         const float* Wq, const float* bq, const float* Wk, const float* bk,
                         const float* Wv, const float* bv, float* out, int64_t ld_out,
                         void* stream);
+/* "Wide" attention for any d that is a multiple of 32 (e.g. the MovieLens configuration, d = 128,
+ * whose three [d, d] weights and Q|K|V tiles do not fit LDS together): Q|K|V by MFMA products
+ * (sagnn_dense_nn_f32's kernel) into caller scratch [n, t, 3d], then a per-node attention kernel.
+ * sagnn_interval_fusion_f32 and the Python wrappers route here automatically; the LSTM keeps its
+ * VALU form for such d. */
+size_t sagnn_mhsa_wide_workspace_bytes(int64_t n, int t, int d);
+int sagnn_mhsa_mean_wide_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
+                             const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv,
+                             const float* bv, float* out, int64_t ld_out, void* workspace, size_t workspace_bytes,
+                             void* stream);
 int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
                               const float* lstm_W, const float* lstm_b, float forget_bias,
                               const float* ln_gamma, const float* ln_beta, float ln_eps,
@@ -351,7 +361,8 @@ int sagnn_adam_step_f32(float* param, const float* grad, float* m, float* v, int
  *   sagnn_dense_tn_f32:  dW[din, dout] += X[n, din]^T @ G[n, dout];  db[dout] += column sums of G
  *       (db nullable). The weight-gradient products; accumulates with float atomics, so zero
  *       dW/db first and expect run-to-run differences in the last bits.
- * din, dout: multiples of 32, dout <= 256 (tn: din <= 256 too); din*dout*4 bytes must fit LDS.
+ * din, dout: any multiples of 32; products whose W block exceeds LDS or 256 columns are cut into
+ * column slices / K chunks internally (later chunks accumulate).
  * -------------------------------------------------------------------------------- */
 int sagnn_dense_nn_f32(const float* X, int64_t ldx, int64_t n, int din, int dout, const float* W,
                        const float* bias, float* Y, int64_t ldy, int accumulate, void* stream);

@@ -25,7 +25,7 @@ __device__ __forceinline__ int crow(int r, int rh) { return (r & 3) + 8 * (r >> 
 template <int CT>
 __global__ __launch_bounds__(kBlock, 1) void dense_nn_kernel(const float* __restrict__ X, int64_t ldx,
                                                              int64_t n, int din,
-                                                             const float* __restrict__ W,
+                                                             const float* __restrict__ W, int64_t ldw,
                                                              const float* __restrict__ bias,
                                                              float* __restrict__ Y, int64_t ldy,
                                                              int accumulate, int64_t n_tiles) {
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(kBlock, 1) void dense_nn_kernel(const float* __rest
     const int rest = idx >> 6;
     const int ct = rest % CT;
     const int kk = rest / CT;
-    Wf[idx] = W[(size_t)(2 * kk + (l >> 5)) * DOUT + ct * 32 + (l & 31)];
+    Wf[idx] = W[(size_t)(2 * kk + (l >> 5)) * ldw + ct * 32 + (l & 31)];
   }
   __syncthreads();
   float bcol[CT];
@@ -135,7 +135,7 @@ template <int TPW>
 __global__ __launch_bounds__(kBlock, 1) void dense_tn_kernel(const float* __restrict__ X, int64_t ldx,
                                                              const float* __restrict__ G, int64_t ldg,
                                                              int64_t n, int din, int dout,
-                                                             float* __restrict__ dW,
+                                                             float* __restrict__ dW, int64_t lddw,
                                                              float* __restrict__ db, int64_t n_chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* xs = lds;                    // [32][din]
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kBlock, 1) void dense_tn_kernel(const float* __rest
       const int ta = tt / nb, tb = tt - ta * nb;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        atomicAdd(dW + (size_t)(ta * 32 + crow(r, kh)) * dout + tb * 32 + li, acc[j][r]);
+        atomicAdd(dW + (size_t)(ta * 32 + crow(r, kh)) * lddw + tb * 32 + li, acc[j][r]);
     }
   }
   if (db && (int)threadIdx.x < dout) atomicAdd(db + threadIdx.x, colsum);
@@ -215,8 +215,8 @@ int cu_count() {
 }
 
 template <int CT>
-int launch_nn(const float* X, int64_t ldx, int64_t n, int din, const float* W, const float* bias, float* Y,
-              int64_t ldy, int accumulate, hipStream_t s) {
+int launch_nn(const float* X, int64_t ldx, int64_t n, int din, const float* W, int64_t ldw, const float* bias,
+              float* Y, int64_t ldy, int accumulate, hipStream_t s) {
   const size_t lds = ((size_t)din * CT * 32 + 4 * 32 * 32) * sizeof(float);
   if (lds > 160 * 1024) return sagnn::fail(SAGNN_ERR_DIM, "dense_nn: W %d x %d does not fit LDS", din, CT * 32);
   static size_t configured = 0;
@@ -227,15 +227,15 @@ int launch_nn(const float* X, int64_t ldx, int64_t n, int din, const float* W, c
   }
   const int64_t n_tiles = (n + 127) / 128;
   const int64_t blocks = n_tiles < cu_count() ? n_tiles : cu_count();
-  hipLaunchKernelGGL(dense_nn_kernel<CT>, dim3((unsigned)blocks), dim3(kBlock), lds, s, X, ldx, n, din, W, bias, Y,
-                     ldy, accumulate, n_tiles);
+  hipLaunchKernelGGL(dense_nn_kernel<CT>, dim3((unsigned)blocks), dim3(kBlock), lds, s, X, ldx, n, din, W, ldw, bias,
+                     Y, ldy, accumulate, n_tiles);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
 
 template <int TPW>
 int launch_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW,
-              float* db, hipStream_t s) {
+              int64_t lddw, float* db, hipStream_t s) {
   const size_t lds = (size_t)32 * (din + dout) * sizeof(float);
   static size_t configured = 0;
   if (lds > configured) {
@@ -246,7 +246,7 @@ int launch_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t 
   const int64_t n_chunks = (n + 31) / 32;
   const int64_t blocks = n_chunks < cu_count() ? n_chunks : cu_count();
   hipLaunchKernelGGL(dense_tn_kernel<TPW>, dim3((unsigned)blocks), dim3(kBlock), lds, s, X, ldx, G, ldg, n, din,
-                     dout, dW, db, n_chunks);
+                     dout, dW, lddw, db, n_chunks);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
@@ -260,42 +260,93 @@ int check_xy(const char* name, const void* p, int64_t ld, int cols) {
 
 }  // namespace
 
+namespace {
+
+int nn_piece(const float* X, int64_t ldx, int64_t n, int din, int dout, const float* W, int64_t ldw,
+             const float* bias, float* Y, int64_t ldy, int accumulate, hipStream_t s) {
+  switch (dout / 32) {
+    case 1: return launch_nn<1>(X, ldx, n, din, W, ldw, bias, Y, ldy, accumulate, s);
+    case 2: return launch_nn<2>(X, ldx, n, din, W, ldw, bias, Y, ldy, accumulate, s);
+    case 3: return launch_nn<3>(X, ldx, n, din, W, ldw, bias, Y, ldy, accumulate, s);
+    case 4: return launch_nn<4>(X, ldx, n, din, W, ldw, bias, Y, ldy, accumulate, s);
+    case 5: return launch_nn<5>(X, ldx, n, din, W, ldw, bias, Y, ldy, accumulate, s);
+    case 6: return launch_nn<6>(X, ldx, n, din, W, ldw, bias, Y, ldy, accumulate, s);
+    case 7: return launch_nn<7>(X, ldx, n, din, W, ldw, bias, Y, ldy, accumulate, s);
+    default: return launch_nn<8>(X, ldx, n, din, W, ldw, bias, Y, ldy, accumulate, s);
+  }
+}
+
+int tn_piece(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW,
+             int64_t lddw, float* db, hipStream_t s) {
+  const int tiles = (din / 32) * (dout / 32);
+  const int tpw = (tiles + 3) / 4;
+  if (tpw <= 1) return launch_tn<1>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
+  if (tpw <= 2) return launch_tn<2>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
+  if (tpw <= 3) return launch_tn<3>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
+  if (tpw <= 4) return launch_tn<4>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
+  if (tpw <= 8) return launch_tn<8>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
+  return launch_tn<16>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
+}
+
+constexpr int kLdsFloatsForW = (160 * 1024 - 4 * 32 * 32 * 4) / 4;  // what dense_nn can give to W
+
+}  // namespace
+
+namespace sagnn {
+
+// Y (+)= X @ W + bias for ANY din/dout that are multiples of 32: the product is cut into column
+// slices of <= 256 and row (K) chunks whose W block fits LDS; later chunks accumulate.
+int dense_nn_any(const float* X, int64_t ldx, int64_t n, int din, int dout, const float* W, int64_t ldw,
+                 const float* bias, float* Y, int64_t ldy, int accumulate, hipStream_t s) {
+  for (int c0 = 0; c0 < dout; c0 += 256) {
+    const int cw = dout - c0 < 256 ? dout - c0 : 256;
+    int kmax = (kLdsFloatsForW / cw) / 32 * 32;
+    if (kmax > din) kmax = din;
+    for (int k0 = 0; k0 < din; k0 += kmax) {
+      const int kw = din - k0 < kmax ? din - k0 : kmax;
+      if (int rc = nn_piece(X + k0, ldx, n, kw, cw, W + (size_t)k0 * ldw + c0, ldw, (k0 == 0 && bias) ? bias + c0 : nullptr,
+                            Y + c0, ldy, (k0 > 0) ? 1 : accumulate, s))
+        return rc;
+    }
+  }
+  return SAGNN_OK;
+}
+
+// dW += X^T G, db += colsum(G) for any multiples of 32: 256 x 256 output blocks at most per launch.
+int dense_tn_any(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW,
+                 int64_t lddw, float* db, hipStream_t s) {
+  for (int r0 = 0; r0 < din; r0 += 128) {
+    const int rw = din - r0 < 128 ? din - r0 : 128;
+    for (int c0 = 0; c0 < dout; c0 += 256) {
+      const int cw = dout - c0 < 256 ? dout - c0 : 256;
+      if (int rc = tn_piece(X + r0, ldx, G + c0, ldg, n, rw, cw, dW + (size_t)r0 * lddw + c0, lddw,
+                            (r0 == 0 && db) ? db + c0 : nullptr, s))
+        return rc;
+    }
+  }
+  return SAGNN_OK;
+}
+
+}  // namespace sagnn
+
 extern "C" int sagnn_dense_nn_f32(const float* X, int64_t ldx, int64_t n, int din, int dout, const float* W,
                                   const float* bias, float* Y, int64_t ldy, int accumulate, void* stream) {
-  if (n < 0 || din < 32 || dout < 32 || (din & 31) || (dout & 31) || dout > 256)
-    return sagnn::fail(SAGNN_ERR_DIM, "dense_nn: need din, dout multiples of 32, dout <= 256 (got %d, %d)", din, dout);
+  if (n < 0 || din < 32 || dout < 32 || (din & 31) || (dout & 31))
+    return sagnn::fail(SAGNN_ERR_DIM, "dense_nn: need din, dout multiples of 32 (got %d, %d)", din, dout);
   if (int rc = check_xy("X", X, ldx, din)) return rc;
   if (int rc = check_xy("Y", Y, ldy, dout)) return rc;
   if (!W) return sagnn::fail(SAGNN_ERR_NULL, "W is NULL");
   if (n == 0) return SAGNN_OK;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  switch (dout / 32) {
-    case 1: return launch_nn<1>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
-    case 2: return launch_nn<2>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
-    case 3: return launch_nn<3>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
-    case 4: return launch_nn<4>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
-    case 5: return launch_nn<5>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
-    case 6: return launch_nn<6>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
-    case 7: return launch_nn<7>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
-    default: return launch_nn<8>(X, ldx, n, din, W, bias, Y, ldy, accumulate, s);
-  }
+  return sagnn::dense_nn_any(X, ldx, n, din, dout, W, dout, bias, Y, ldy, accumulate, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int sagnn_dense_tn_f32(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din,
                                   int dout, float* dW, float* db, void* stream) {
-  if (n < 0 || din < 32 || dout < 32 || (din & 31) || (dout & 31) || dout > 256 || din > 256)
-    return sagnn::fail(SAGNN_ERR_DIM, "dense_tn: need din, dout multiples of 32 and <= 256 (got %d, %d)", din, dout);
+  if (n < 0 || din < 32 || dout < 32 || (din & 31) || (dout & 31))
+    return sagnn::fail(SAGNN_ERR_DIM, "dense_tn: need din, dout multiples of 32 (got %d, %d)", din, dout);
   if (int rc = check_xy("X", X, ldx, din)) return rc;
   if (int rc = check_xy("G", G, ldg, dout)) return rc;
   if (!dW) return sagnn::fail(SAGNN_ERR_NULL, "dW is NULL");
   if (n == 0) return SAGNN_OK;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int tiles = (din / 32) * (dout / 32);
-  const int tpw = (tiles + 3) / 4;
-  if (tpw <= 1) return launch_tn<1>(X, ldx, G, ldg, n, din, dout, dW, db, s);
-  if (tpw <= 2) return launch_tn<2>(X, ldx, G, ldg, n, din, dout, dW, db, s);
-  if (tpw <= 3) return launch_tn<3>(X, ldx, G, ldg, n, din, dout, dW, db, s);
-  if (tpw <= 4) return launch_tn<4>(X, ldx, G, ldg, n, din, dout, dW, db, s);
-  if (tpw <= 8) return launch_tn<8>(X, ldx, G, ldg, n, din, dout, dW, db, s);
-  return launch_tn<16>(X, ldx, G, ldg, n, din, dout, dW, db, s);
+  return sagnn::dense_tn_any(X, ldx, G, ldg, n, din, dout, dW, dout, db, static_cast<hipStream_t>(stream));
 }

@@ -21,7 +21,8 @@ __global__ void lstm_fwd_valu_kernel(const float* __restrict__ x, int64_t ld_n, 
                                      int64_t n, int t, int d, const float* __restrict__ W,
                                      const float* __restrict__ b, float forget_bias,
                                      const float* __restrict__ drop, float* __restrict__ h_out,
-                                     int64_t ld_h) {
+                                     int64_t ld_h, float* __restrict__ gates_out,
+                                     float* __restrict__ c_out) {
   extern __shared__ float sm[];  // [rows_per_block][2d]: x_t | h
   constexpr int RPT = kLstmRowsPerThread;
   const int j = threadIdx.x % d;
@@ -69,10 +70,20 @@ __global__ void lstm_fwd_valu_kernel(const float* __restrict__ x, int64_t ld_n, 
     for (int r = 0; r < RPT; ++r) {
       const int lr = rs * RPT + r;
       const int64_t row = row_base + lr;
-      const float cn = c[r] * sigmoidf_(gf[r] + b_f + forget_bias) + sigmoidf_(gi[r] + b_i) * tanhf(gj[r] + b_j);
-      const float hn = tanhf(cn) * sigmoidf_(go[r] + b_o);
+      const float si = sigmoidf_(gi[r] + b_i), tj = tanhf(gj[r] + b_j);
+      const float sf = sigmoidf_(gf[r] + b_f + forget_bias), so = sigmoidf_(go[r] + b_o);
+      const float cn = c[r] * sf + si * tj;
+      const float hn = tanhf(cn) * so;
       c[r] = cn;
       sm[lr * d2 + d + j] = hn;
+      if (gates_out && row < n) {  // training forward: activations + cell state for the backward pass
+        float* gp = gates_out + (row * t + ts) * (int64_t)d4 + j;
+        gp[0] = si;
+        gp[d] = tj;
+        gp[2 * d] = sf;
+        gp[3 * d] = so;
+        c_out[(row * t + ts) * (int64_t)d + j] = cn;
+      }
       if (row < n) {
         const int64_t o = row * ld_h + (int64_t)ts * d + j;
         h_out[o] = drop ? hn * drop[row * (int64_t)t * d + (int64_t)ts * d + j] : hn;
@@ -172,6 +183,53 @@ __global__ void mhsa_mean_valu_kernel(const float* __restrict__ x, int64_t ld_n,
   }
 }
 
+
+// ---- "wide" attention: any d that is a multiple of 32 (e.g. 128): Q|K|V by the MFMA dense products
+// of dense.hip into a [n, t, 3d] buffer, then this per-node kernel. (The LSTM keeps its VALU form
+// for such d: an un-fused MFMA composition measured no faster, 37.5 vs 37.2 ms at n = 1M, d = 128,
+// T = 6 — the gate round trip through HBM eats the MFMA gain.) ---------------------------------------
+
+// Attention + mean over queries from a Q|K|V buffer [n, t, 3d] (rows as x@W+b produced them).
+__global__ void attn_mean_from_qkv_kernel(const float* __restrict__ qkv, int64_t n, int t, int d, int heads,
+                                          float* __restrict__ out, int64_t ld_out) {
+  extern __shared__ float sm[];
+  const int j = threadIdx.x % d;
+  const int slot = threadIdx.x / d;
+  const int slots = blockDim.x / d;
+  const int td = t * d;
+  float* qs = sm + (size_t)slot * 3 * td;
+  float* ks = qs + td;
+  float* vs = ks + td;
+  const int dk = d / heads;
+  const int hoff = (j / dk) * dk;
+  const float scale = 1.f / sqrtf((float)dk);
+  for (int64_t node0 = (int64_t)blockIdx.x * slots; node0 < n; node0 += (int64_t)gridDim.x * slots) {
+    const int64_t node = node0 + slot;
+    const bool valid = node < n;
+    const float* row = qkv + (valid ? node : 0) * (int64_t)(3 * td);
+    for (int ts = 0; ts < t; ++ts) {
+      qs[ts * d + j] = row[ts * 3 * d + j];
+      ks[ts * d + j] = row[ts * 3 * d + d + j];
+      vs[ts * d + j] = row[ts * 3 * d + 2 * d + j];
+    }
+    __syncthreads();
+    float o = 0.f;
+    for (int tq = 0; tq < t; ++tq) {
+      float rowsum = 0.f, ctx = 0.f;
+      for (int s2 = 0; s2 < t; ++s2) {
+        float dot = 0.f;
+        for (int c = 0; c < dk; ++c) dot = fmaf(qs[tq * d + hoff + c], ks[s2 * d + hoff + c], dot);
+        const float e = expf(dot * scale);
+        rowsum += e;
+        ctx = fmaf(e, vs[s2 * d + j], ctx);
+      }
+      o += ctx / (rowsum + 1e-8f);
+    }
+    if (valid) out[node * ld_out + j] = o / (float)t;
+    __syncthreads();
+  }
+}
+
 int check_dims(int64_t n, int t, int d) {
   if (n < 0) return sagnn::fail(SAGNN_ERR_ARG, "n = %lld < 0", (long long)n);
   if (t < 1 || t > 64) return sagnn::fail(SAGNN_ERR_DIM, "t = %d: need 1..64", t);
@@ -197,7 +255,7 @@ namespace sagnn {
 
 int lstm_fwd_valu(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
                   const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
-                  hipStream_t s) {
+                  float* gates_out, float* c_out, hipStream_t s) {
   const int slots = kBlock / d > 0 ? kBlock / d : 1;
   const int threads = slots * d;
   const int rows_pb = slots * kLstmRowsPerThread;
@@ -206,7 +264,7 @@ int lstm_fwd_valu(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, 
   const size_t lds = (size_t)rows_pb * 2 * d * sizeof(float);
   ProfileScope prof(kProfLstm, s, n, t);
   hipLaunchKernelGGL(lstm_fwd_valu_kernel, dim3((unsigned)blocks), dim3(threads), lds, s, x, ld_n, ld_t,
-                     n, t, d, W, b, forget_bias, drop, h, ld_h);
+                     n, t, d, W, b, forget_bias, drop, h, ld_h, gates_out, c_out);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
@@ -229,6 +287,66 @@ int mhsa_mean_valu(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t,
 
 }  // namespace sagnn
 
+
+namespace sagnn {
+
+bool wide_supported(int d) { return d % 32 == 0 && d >= 32 && d <= 256; }
+
+// MHSA + mean for any d % 32 == 0: Q|K|V by three MFMA products per interval into ws [n, t, 3d],
+// then the per-node attention kernel.
+int mhsa_mean_wide(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads, const float* Wq,
+                   const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv, float* out,
+                   int64_t ld_out, float* ws, hipStream_t s) {
+  ProfileScope prof(kProfMhsa, s, n, t);
+  const int64_t ldq = (int64_t)t * 3 * d;
+  for (int ts = 0; ts < t; ++ts) {
+    const float* xt = x + (int64_t)ts * ld_t;
+    float* qt = ws + (int64_t)ts * 3 * d;
+    if (int rc = dense_nn_any(xt, ld_n, n, d, d, Wq, d, bq, qt, ldq, 0, s)) return rc;
+    if (int rc = dense_nn_any(xt, ld_n, n, d, d, Wk, d, bk, qt + d, ldq, 0, s)) return rc;
+    if (int rc = dense_nn_any(xt, ld_n, n, d, d, Wv, d, bv, qt + 2 * d, ldq, 0, s)) return rc;
+  }
+  int slots = kBlock / d > 0 ? kBlock / d : 1;
+  while (slots > 1 && (size_t)slots * 3 * t * d * sizeof(float) > 64 * 1024) slots >>= 1;
+  const size_t lds = (size_t)slots * 3 * t * d * sizeof(float);
+  if (lds > 160 * 1024) return fail(SAGNN_ERR_DIM, "t*d = %d too large for LDS", t * d);
+  static size_t configured = 0;
+  if (lds > configured) {
+    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mean_from_qkv_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = lds;
+  }
+  int64_t blocks = (n + slots - 1) / slots;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(attn_mean_from_qkv_kernel, dim3((unsigned)blocks), dim3(slots * d), lds, s, ws, n, t, d, heads,
+                     out, ld_out);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+}  // namespace sagnn
+
+extern "C" size_t sagnn_mhsa_wide_workspace_bytes(int64_t n, int t, int d) {
+  return (n <= 0 || d <= 0 || t <= 0) ? 0 : (size_t)n * (size_t)t * 3 * (size_t)d * sizeof(float);
+}
+
+extern "C" int sagnn_mhsa_mean_wide_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
+                                        int heads, const float* Wq, const float* bq, const float* Wk,
+                                        const float* bk, const float* Wv, const float* bv, float* out,
+                                        int64_t ld_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (int rc = check_dims(n, t, d)) return rc;
+  if (!sagnn::wide_supported(d)) return sagnn::fail(SAGNN_ERR_DIM, "d = %d: the wide path needs a multiple of 32", d);
+  if (heads < 1 || d % heads) return sagnn::fail(SAGNN_ERR_DIM, "heads = %d does not divide d = %d", heads, d);
+  if (!x || !Wq || !bq || !Wk || !bk || !Wv || !bv || !out) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (int rc = check_strides(ld_n, ld_t, n, t, d)) return rc;
+  if ((ld_n & 3) || (ld_t & 3) || !sagnn::aligned16(x)) return sagnn::fail(SAGNN_ERR_ALIGN, "x rows must be 16-byte aligned");
+  if (n == 0) return SAGNN_OK;
+  if (!workspace || workspace_bytes < sagnn_mhsa_wide_workspace_bytes(n, t, d))
+    return sagnn::fail(SAGNN_ERR_WORKSPACE, "mhsa wide workspace needs %zu bytes", sagnn_mhsa_wide_workspace_bytes(n, t, d));
+  return sagnn::mhsa_mean_wide(x, ld_n, ld_t, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out,
+                               static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
+}
+
 extern "C" int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
                                   const float* W, const float* b, float forget_bias,
                                   const float* drop_scale, float* h, int64_t ld_h, void* stream) {
@@ -243,7 +361,7 @@ extern "C" int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t ld_t, in
   if (sagnn::lstm_mfma_supported(d) && vec_ok && !sagnn::force_valu())
     return sagnn::lstm_fwd_mfma(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, nullptr,
                                 nullptr, static_cast<hipStream_t>(stream));
-  return sagnn::lstm_fwd_valu(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h,
+  return sagnn::lstm_fwd_valu(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, nullptr, nullptr,
                               static_cast<hipStream_t>(stream));
 }
 
@@ -283,9 +401,13 @@ extern "C" int sagnn_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t ld_t, i
                                static_cast<hipStream_t>(stream));
 }
 
+static bool use_wide(int d) { return !sagnn::lstm_mfma_supported(d) && sagnn::wide_supported(d) && !sagnn::force_valu(); }
+
 extern "C" size_t sagnn_interval_fusion_workspace_bytes(int64_t n, int t, int d) {
   if (n <= 0 || t <= 0 || d <= 0) return 0;
-  return (size_t)n * (size_t)t * (size_t)d * sizeof(float);  // h, normalised in place
+  size_t bytes = (size_t)n * (size_t)t * (size_t)d * sizeof(float);  // h, normalised in place
+  if (use_wide(d)) bytes += sagnn_mhsa_wide_workspace_bytes(n, t, d);  // Q|K|V of the wide attention
+  return bytes;
 }
 
 extern "C" int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t,
@@ -305,8 +427,15 @@ extern "C" int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t l
   if (heads < 1 || d % heads) return sagnn::fail(SAGNN_ERR_DIM, "heads = %d does not divide d = %d", heads, d);
   if (!ln_gamma || !ln_beta || !Wq || !bq || !Wk || !bk || !Wv || !bv || !out)
     return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
-  if (int rc = sagnn_lstm_fwd_f32(x, ld_n, ld_t, n, t, d, lstm_W, lstm_b, forget_bias, nullptr, h, ldw, stream)) return rc;
   if (n == 0) return SAGNN_OK;
+  if (use_wide(d)) {  // d = 96, 128, ...: VALU LSTM, MFMA products + per-node kernel for the attention
+    float* scratch = h + n * ldw;
+    const size_t sbytes = workspace_bytes - (size_t)n * ldw * sizeof(float);
+    if (int rc = sagnn_lstm_fwd_f32(x, ld_n, ld_t, n, t, d, lstm_W, lstm_b, forget_bias, nullptr, h, ldw, stream)) return rc;
+    if (int rc = sagnn_layernorm_td_f32(h, ldw, d, n, t, d, ln_gamma, ln_beta, ln_eps, h, ldw, stream)) return rc;
+    return sagnn_mhsa_mean_wide_f32(h, ldw, d, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out, scratch, sbytes, stream);
+  }
+  if (int rc = sagnn_lstm_fwd_f32(x, ld_n, ld_t, n, t, d, lstm_W, lstm_b, forget_bias, nullptr, h, ldw, stream)) return rc;
   // layer norm rides on the attention kernel's A operand when the matrix-core path applies:
   // h is read once and never rewritten
   if (sagnn::mhsa_mfma_supported(d, t, heads) && !sagnn::force_valu())
@@ -325,9 +454,11 @@ extern "C" int sagnn_lstm_fwd_train_f32(const float* x, int64_t ld_n, int64_t ld
   if (!x || !W || !b || !h || !gates || !cell) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
   if (int rc = check_strides(ld_n, ld_t, n, t, d)) return rc;
   if (ld_h < (int64_t)t * d) return sagnn::fail(SAGNN_ERR_ARG, "ld_h smaller than t*d");
-  if (!sagnn::lstm_mfma_supported(d)) return sagnn::fail(SAGNN_ERR_DIM, "training path supports d = 32 or 64, got %d", d);
-  if (!sagnn::aligned16(x) || (ld_n & 3) || (ld_t & 3)) return sagnn::fail(SAGNN_ERR_ALIGN, "x rows must be 16-byte aligned");
   if (n == 0) return SAGNN_OK;
-  return sagnn::lstm_fwd_mfma(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, gates, cell,
+  const bool vec_ok = sagnn::aligned16(x) && (ld_n & 3) == 0 && (ld_t & 3) == 0;
+  if (sagnn::lstm_mfma_supported(d) && vec_ok && !sagnn::force_valu())
+    return sagnn::lstm_fwd_mfma(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, gates, cell,
+                                static_cast<hipStream_t>(stream));
+  return sagnn::lstm_fwd_valu(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, gates, cell,
                               static_cast<hipStream_t>(stream));
 }

@@ -234,6 +234,12 @@ def _vec(name: str, v: torch.Tensor, numel: int):
     return v.data_ptr()
 
 
+def _wide(d: int) -> bool:
+    """d handled by the 'wide' MFMA composition (multiples of 32 other than the fused 32 / 64)."""
+    import os
+    return d % 32 == 0 and d not in (32, 64) and os.environ.get("SAGNN_FUSION") != "valu"
+
+
 def lstm_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, forget_bias: float = 1.0,
              drop_scale: torch.Tensor | None = None, out: torch.Tensor | None = None):
     """BasicLSTMCell over T (reference model.py:135-146): sagnn_lstm_fwd_f32. x [n, t, d]."""
@@ -243,9 +249,10 @@ def lstm_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, forget_bias: flo
     _, _, _, ldh, _ = _ntd("out", out, dense_td=True)
     if drop_scale is not None and (not drop_scale.is_contiguous() or drop_scale.shape != x.shape):
         raise ValueError("drop_scale must be contiguous [n, t, d]")
-    check(_lib.load().sagnn_lstm_fwd_f32(x.data_ptr(), ld, ldt, n, t, d, _vec("W", W, 8 * d * d),
-                                         _vec("b", b, 4 * d), float(forget_bias), _ptr(drop_scale),
-                                         out.data_ptr(), ldh, _stream()))
+    lib = _lib.load()
+    check(lib.sagnn_lstm_fwd_f32(x.data_ptr(), ld, ldt, n, t, d, _vec("W", W, 8 * d * d),
+                                 _vec("b", b, 4 * d), float(forget_bias), _ptr(drop_scale),
+                                 out.data_ptr(), ldh, _stream()))
     return out
 
 
@@ -269,7 +276,15 @@ def mhsa_mean(x: torch.Tensor, Wq, bq, Wk, bk, Wv, bv, heads: int, out: torch.Te
     if out is None:
         out = torch.empty((n, d), dtype=torch.float32, device=x.device)
     ldo = _f32_rows("out", out, d, n)
-    check(_lib.load().sagnn_mhsa_mean_f32(
+    lib = _lib.load()
+    if _wide(d):
+        ws = torch.empty(int(lib.sagnn_mhsa_wide_workspace_bytes(n, t, d)) // 4, dtype=torch.float32, device=x.device)
+        check(lib.sagnn_mhsa_mean_wide_f32(
+            x.data_ptr(), ld, ldt, n, t, d, int(heads), _vec("Wq", Wq, d * d), _vec("bq", bq, d),
+            _vec("Wk", Wk, d * d), _vec("bk", bk, d), _vec("Wv", Wv, d * d), _vec("bv", bv, d),
+            out.data_ptr(), ldo, ws.data_ptr(), ws.numel() * 4, _stream()))
+        return out
+    check(lib.sagnn_mhsa_mean_f32(
         x.data_ptr(), ld, ldt, n, t, d, int(heads), _vec("Wq", Wq, d * d), _vec("bq", bq, d),
         _vec("Wk", Wk, d * d), _vec("bk", bk, d), _vec("Wv", Wv, d * d), _vec("bv", bv, d),
         out.data_ptr(), ldo, _stream()))

@@ -6,7 +6,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,din,dout", [(1000, 64, 192), (129, 192, 64), (5000, 256, 128), (31, 32, 96), (300, 96, 32), (4097, 128, 256)])
+@pytest.mark.parametrize("n,din,dout", [(1000, 64, 192), (129, 192, 64), (5000, 256, 128), (31, 32, 96), (300, 96, 32), (4097, 128, 256), (700, 512, 128), (333, 128, 512), (200, 256, 384)])
 def test_dense_nn(dev, n, din, dout):
     from sa_gnn_amd import ops
     g = torch.Generator(device="cpu").manual_seed(n + din)
@@ -25,7 +25,7 @@ def test_dense_nn(dev, n, din, dout):
     assert torch.all(out[:, dout:] == 1)
 
 
-@pytest.mark.parametrize("n,din,dout", [(1000, 64, 192), (77, 128, 256), (20000, 128, 256), (513, 32, 96), (64, 192, 64), (999, 256, 128)])
+@pytest.mark.parametrize("n,din,dout", [(1000, 64, 192), (77, 128, 256), (20000, 128, 256), (513, 32, 96), (64, 192, 64), (999, 256, 128), (450, 256, 512), (300, 384, 128)])
 def test_dense_tn(dev, n, din, dout):
     from sa_gnn_amd import ops
     gen = torch.Generator(device="cpu").manual_seed(n + dout)

@@ -103,6 +103,8 @@ def test_fusion_argument_errors_without_gpu():
     assert lib.sagnn_lstm_fwd_f32(None, 0, 0, 4, 2, 62, None, None, 1.0, None, None, 0, None) == -2
     assert lib.sagnn_mhsa_mean_f32(None, 0, 0, 4, 2, 64, 7, None, None, None, None, None, None, None, 0, None) == -2
     assert lib.sagnn_interval_fusion_workspace_bytes(10, 3, 64) == 10 * 3 * 64 * 4
+    assert lib.sagnn_interval_fusion_workspace_bytes(10, 3, 128) == 10 * 3 * 128 * 4 + 10 * 3 * 3 * 128 * 4
+    assert lib.sagnn_interval_fusion_workspace_bytes(10, 3, 48) == 10 * 3 * 48 * 4
     assert lib.sagnn_layernorm_td_f32(None, 0, 0, 0, 0, 64, None, None, 1e-12, None, 0, None) == -2
 
 
