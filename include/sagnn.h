@@ -275,6 +275,11 @@ size_t sagnn_interval_fusion_workspace_bytes(int64_t n, int t, int d);
  *   h, scaled by drop_scale if given), dh_rec [n, d] (recurrent gradient, NULL at the last step),
  *   dc_in [n, d] (NULL at the last step) -> dgates [n, 4d] (pre-activation gradients, i|j|f|o)
  *   and dc_out [n, d].
+ * sagnn_lstm_bwd_f32 — the whole BPTT in one launch (d in {32, 64}; sagnn_lstm_bwd_supported):
+ *   x as given to the forward, h/gates/cell as sagnn_lstm_fwd_train_f32 stored them (h un-dropped,
+ *   [n, t, d] dense), dh_ext [n, t, d] with row stride ld_dhe -> dx [n, t, d] dense, and
+ *   dW [2d, 4d] / db [4d] ACCUMULATED with float atomics (zero them first). Gate gradients stay
+ *   on chip: per 32-row chunk and step, d[x|h] = dG W^T and dW += [x|h]^T dG run as MFMA tiles.
  * -------------------------------------------------------------------------------- */
 int sagnn_lstm_fwd_train_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
                              const float* W, const float* b, float forget_bias, const float* drop_scale,
@@ -287,6 +292,10 @@ int sagnn_layernorm_td_bwd_f32(const float* h, int64_t ld_h, const float* dy, in
 int sagnn_lstm_bwd_step_f32(const float* gates, const float* cell, const float* dh_ext, int64_t ld_dhe,
                             const float* drop_scale, const float* dh_rec, int64_t ld_dhr, const float* dc_in,
                             float* dgates, float* dc_out, int64_t n, int t, int d, int ts, void* stream);
+int sagnn_lstm_bwd_supported(int d);
+int sagnn_lstm_bwd_f32(const float* x, int64_t ld_n, int64_t ld_t, const float* h, const float* gates,
+                       const float* cell, const float* dh_ext, int64_t ld_dhe, const float* drop_scale,
+                       const float* W, float* dx, float* dW, float* db, int64_t n, int t, int d, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Prediction head (reference model.py:156-173). The masked sum of item /

@@ -74,6 +74,9 @@ SIGNATURES = {
                                            c_float, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "sagnn_lstm_bwd_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                         c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "sagnn_lstm_bwd_supported": (c_int, [c_int]),
+    "sagnn_lstm_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "sagnn_leaky_add_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     "sagnn_pair_score_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                      c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_void_p]),

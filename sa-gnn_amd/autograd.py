@@ -3,6 +3,8 @@
 libsagnn.so; torch only carries the graph."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -45,6 +47,30 @@ class GnnIntervalFn(torch.autograd.Function):
 
 def gnn_interval(u0, i0, plan_user, plan_item, n_layers: int, leaky: float):
     return GnnIntervalFn.apply(u0, i0, plan_user, plan_item, n_layers, leaky)
+
+
+def _split_qkv_grads(dWqkv, dbqkv, d):
+    """[d, 3d] / [3d] -> (dWq, dbq, dWk, dbk, dWv, dbv)."""
+    out = ()
+    for i in range(3):
+        out += (dWqkv[:, i * d:(i + 1) * d].contiguous(), dbqkv[i * d:(i + 1) * d].contiguous())
+    return out
+
+
+def lstm_bwd(x, h, gates, cell, dh, drop, W):
+    """Whole BPTT in one launch (sagnn_lstm_bwd_f32, d in {32, 64}): x [n, t, d] (any strides),
+    h / gates / cell as the training forward stored them, dh [n, t, d] dense = gradient at the
+    emitted h -> (dx [n, t, d], dW [2d, 4d], db [4d])."""
+    lib = ops._lib.load()
+    n, t, d, ld_n, ld_t = ops._ntd("x", x)
+    dev = x.device
+    dx = torch.empty((n, t, d), dtype=torch.float32, device=dev)
+    dW = torch.zeros((2 * d, 4 * d), dtype=torch.float32, device=dev)
+    db = torch.zeros(4 * d, dtype=torch.float32, device=dev)
+    ops.check(lib.sagnn_lstm_bwd_f32(x.data_ptr(), ld_n, ld_t, h.data_ptr(), gates.data_ptr(), cell.data_ptr(),
+                                     dh.data_ptr(), t * d, ops._ptr(drop), ops._vec("lstm_W", W, 8 * d * d),
+                                     dx.data_ptr(), dW.data_ptr(), db.data_ptr(), n, t, d, ops._stream()))
+    return dx, dW, db
 
 
 class IntervalFusionFn(torch.autograd.Function):
@@ -112,6 +138,9 @@ class IntervalFusionFn(torch.autograd.Function):
                                                  ops._vec("gamma", ln_gamma.detach(), d), 1e-12, dh.data_ptr(),
                                                  t * d, dgamma.data_ptr(), dbeta.data_ptr(), st))
         # ---- BPTT ----------------------------------------------------------------------------------
+        if lib.sagnn_lstm_bwd_supported(d) and os.environ.get("SAGNN_BPTT", "") != "steps":
+            dx, dW, db = lstm_bwd(x, h, gates, cell, dh, drop, lstm_W.detach())
+            return (dx, dW, db, dgamma, dbeta) + _split_qkv_grads(dWqkv, dbqkv, d) + (None, None)
         Wd = lstm_W.detach()
         WxT = Wd[:d].t().contiguous()                                                    # [4d, d]
         WhT = Wd[d:].t().contiguous()
@@ -134,9 +163,7 @@ class IntervalFusionFn(torch.autograd.Function):
                 ops.dense_tn(h_state[:, ts - 1, :], dgates, dW[d:], None)
                 ops.dense_nn(dgates, WhT, None, out=dh_rec)
             ops.dense_nn(dgates, WxT, None, out=dx[:, ts, :])
-        dWq, dWk, dWv = (dWqkv[:, i * d:(i + 1) * d].contiguous() for i in range(3))
-        dbq, dbk, dbv = (dbqkv[i * d:(i + 1) * d].contiguous() for i in range(3))
-        return dx, dW, db, dgamma, dbeta, dWq, dbq, dWk, dbk, dWv, dbv, None, None
+        return (dx, dW, db, dgamma, dbeta) + _split_qkv_grads(dWqkv, dbqkv, d) + (None, None)
 
 
 def interval_fusion(x, p: dict, heads: int, drop_scale=None):

@@ -1,0 +1,332 @@
+// Whole BPTT of the BasicLSTMCell (gradient of reference model.py:135-146) in one launch.
+//
+// The un-fused form (sagnn_lstm_bwd_step_f32 + two dense products per step) writes the gate
+// gradients [n, 4d] to HBM and reads them back twice per step, and its products run at a third of
+// the MFMA rate. Here a block (4 waves, one per SIMD) walks 32-row chunks through all T steps:
+//
+//   phase A (VALU, 256 threads): saved activations + dh -> gate gradients dG [32, 4D] into LDS
+//   MFMA 1: d[x_t | h_{t-1}] [32, 2D] = dG @ W^T      one 32-column tile per wave; its slice of W^T
+//           sits in LDS as ready-made B fragments (one ds_read_b128 per 4 MFMAs), except the
+//           8 KB per block that do not fit the 160 KB next to the tiles: those stay in registers
+//   MFMA 2: dW [2D, 4D] += [x_t | h_{t-1}]^T @ dG     wave w owns tile row w (D = 64: 8 tiles =
+//           128 accumulator registers, kept across every chunk of the block, flushed once)
+//
+// dh_{t-1} goes back through an LDS tile to the next step's phase A; dc stays in registers; dG
+// never leaves the CU. Global operands of the next step are requested before the MFMAs.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBlock = 256;
+constexpr int kRows = 32;  // rows per chunk
+
+__device__ __forceinline__ int crow(int r, int rh) { return (r & 3) + 8 * (r >> 2) + 4 * rh; }
+__device__ __forceinline__ float fast_tanh(float x) {
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * x));
+}
+// float4-slot swizzle of the dG tile: a bijection of the low 4 row bits whose bit 3 flips between
+// rows 2k and 2k+1, so the row-per-lane b128 reads (MFMA 1), the two-rows-per-instruction b32
+// reads (MFMA 2) and the row-major float4 fill are all bank-conflict free.
+__device__ __forceinline__ int swz(int row) { return (row & 15) ^ ((row & 1) << 3); }
+
+template <int D>
+__global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
+    const float* __restrict__ x, int64_t ld_n, int64_t ld_t, const float* __restrict__ h,
+    const float* __restrict__ gates, const float* __restrict__ cell, const float* __restrict__ dh_ext,
+    int64_t ld_dhe, const float* __restrict__ drop, const float* __restrict__ W, float* __restrict__ dx,
+    float* __restrict__ dW, float* __restrict__ db, int64_t n, int t, int64_t n_chunks) {
+  constexpr int NC = 4 * D;         // gate columns
+  constexpr int S4 = NC / 4;        // float4 slots per dG row
+  constexpr int XT = D / 32;        // column tiles of x (and of h)
+  constexpr int TA = 2 * XT;        // tile rows of dW = column tiles of [x | h]
+  constexpr int TB = NC / 32;       // tile columns of dW
+  constexpr int WPT = 4 / TA;       // waves sharing one tile row (1 at D=64, 2 at D=32)
+  constexpr int NTB = TB / WPT;     // dW tiles per wave
+  constexpr int NQ = NC / 8;        // b128 A reads of MFMA 1
+  constexpr int QR = D == 64 ? 2 : 0;  // of which W^T fragments held in registers (rest: LDS)
+  constexpr int QL = NQ - QR;
+  constexpr int LPR = D / 4;        // phase A: threads per row
+  constexpr int RPP = kBlock / LPR; // rows per pass
+  constexpr int NPASS = kRows / RPP;
+  static_assert(TA <= 4 && 4 % TA == 0 && NPASS >= 1, "D must be 32 or 64");
+
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* dg = lds;                   // [32][NC], slot-swizzled
+  float* dhr = lds + kRows * NC;     // [32][D] recurrent dh for the next (earlier) step
+  float4* wl = reinterpret_cast<float4*>(dhr + kRows * D);  // [NW1][QL][64] W^T fragments
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, kh = lane >> 5;
+  const int ta = wave % TA;          // my tile row of dW / my column tile of d[x|h]
+  const int tb0 = wave / TA;         // my dW tile columns: tb0 + j*WPT
+  const bool mfma1_wave = wave < TA; // D=32: waves 2,3 have no MFMA-1 tile
+  const bool h_side = ta >= XT;      // my [x|h] columns belong to h
+
+  // ---- W^T B fragments for output column tile `ta`: fragment q of lane (li, kh) =
+  // W[32ta+li][8q+4kh .. +3], i.e. the B operands of MFMAs 4q .. 4q+3 (k order matches the b128
+  // A reads of the dG tile)
+  float wb[QR > 0 ? 4 * QR : 1];
+  if (mfma1_wave) {
+    const float* wrow = W + (size_t)(32 * ta + li) * NC + 4 * kh;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(wrow + 8 * q);
+      if (q < QR) {
+        wb[4 * q + 0] = v.x;
+        wb[4 * q + 1] = v.y;
+        wb[4 * q + 2] = v.z;
+        wb[4 * q + 3] = v.w;
+      } else {
+        wl[(wave * QL + (q - QR)) * 64 + lane] = v;
+      }
+    }
+  }
+  // (each wave reads back only what it wrote: no block barrier needed before the first MFMA 1,
+  // and the loop's own barriers come first anyway)
+
+  f32x16 accw[NTB];
+#pragma unroll
+  for (int j = 0; j < NTB; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[j][r] = 0.f;
+  float dbs[4][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dbs[g][e] = 0.f;
+
+  const int prow = tid / LPR, pc4 = tid % LPR;  // phase A: row within pass, float4 column
+
+  // (chunk, step) items form ONE sequence, so the operands of a chunk's first step are requested
+  // under the MFMAs of the previous chunk's last step.
+  float4 dc[NPASS];
+  float4 pg[NPASS][4], pcl[NPASS], pcp[NPASS], pdh[NPASS], pdr[NPASS];
+  // Branch-free: rows past n read row n-1 and are zeroed in phase A (a zero dh makes every gate
+  // gradient of the row zero); the missing c_{-1} of step 0 reads c_0 and is zeroed there too.
+  auto prefetch = [&](int64_t row0, int ts) {
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int64_t grow = row0 + p * RPP + prow;
+      const int64_t gr = grow < n ? grow : n - 1;
+      const int64_t e = gr * t + ts;
+      const float* gp = gates + e * NC + 4 * pc4;
+      pg[p][0] = *reinterpret_cast<const float4*>(gp);
+      pg[p][1] = *reinterpret_cast<const float4*>(gp + D);
+      pg[p][2] = *reinterpret_cast<const float4*>(gp + 2 * D);
+      pg[p][3] = *reinterpret_cast<const float4*>(gp + 3 * D);
+      pcl[p] = *reinterpret_cast<const float4*>(cell + e * D + 4 * pc4);
+      pcp[p] = *reinterpret_cast<const float4*>(cell + (e - (ts > 0)) * D + 4 * pc4);
+      pdh[p] = *reinterpret_cast<const float4*>(dh_ext + gr * ld_dhe + (int64_t)ts * D + 4 * pc4);
+      // applied in phase A: multiplying here would wait for the loads right away
+      if (drop) pdr[p] = *reinterpret_cast<const float4*>(drop + e * D + 4 * pc4);
+    }
+  };
+
+  int64_t ch = blockIdx.x;
+  int ts = t - 1;
+  if (ch < n_chunks) prefetch(ch * kRows, ts);
+  while (ch < n_chunks) {
+    const int64_t row0 = ch * kRows;
+    const int64_t nch = ts > 0 ? ch : ch + gridDim.x;
+    const int nts = ts > 0 ? ts - 1 : t - 1;
+    // lane-derived offsets are re-materialised per step (cheap) instead of being hoisted
+    int li_ = li, kh_ = kh, prow_ = prow, pc4_ = pc4;
+    asm volatile("" : "+v"(li_), "+v"(kh_), "+v"(prow_), "+v"(pc4_));
+
+    // ---- phase A: gate gradients of this step into the dG tile ----------------------------------
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int row = p * RPP + prow_;
+      float4 dhv = pdh[p];
+      const bool valid = row0 + row < n;
+      const float4 sc = drop ? pdr[p] : make_float4(1.f, 1.f, 1.f, 1.f);
+      dhv.x *= valid ? sc.x : 0.f;
+      dhv.y *= valid ? sc.y : 0.f;
+      dhv.z *= valid ? sc.z : 0.f;
+      dhv.w *= valid ? sc.w : 0.f;
+      const float cpm = ts > 0 ? 1.f : 0.f;  // c_{-1} = 0
+      if (ts < t - 1) {
+        const float4 r = *reinterpret_cast<const float4*>(dhr + row * D + 4 * pc4_);
+        dhv.x += r.x;
+        dhv.y += r.y;
+        dhv.z += r.z;
+        dhv.w += r.w;
+      } else {
+        dc[p] = make_float4(0.f, 0.f, 0.f, 0.f);  // first (= last in time) step of a chunk
+      }
+      float4 o_i, o_j, o_f, o_o;
+#define SAGNN_GATE_BWD(e)                                                        \
+  {                                                                              \
+    const float gi = pg[p][0].e, gj = pg[p][1].e, gf = pg[p][2].e, go = pg[p][3].e; \
+    const float tc = fast_tanh(pcl[p].e);                                        \
+    const float dcv = dc[p].e + dhv.e * go * (1.f - tc * tc);                    \
+    o_o.e = dhv.e * tc * go * (1.f - go);                                        \
+    o_i.e = dcv * gj * gi * (1.f - gi);                                          \
+    o_j.e = dcv * gi * (1.f - gj * gj);                                          \
+    o_f.e = dcv * (pcp[p].e * cpm) * gf * (1.f - gf);                                  \
+    dc[p].e = dcv * gf;                                                          \
+  }
+      SAGNN_GATE_BWD(x)
+      SAGNN_GATE_BWD(y)
+      SAGNN_GATE_BWD(z)
+      SAGNN_GATE_BWD(w)
+#undef SAGNN_GATE_BWD
+      float4* drow = reinterpret_cast<float4*>(dg) + row * S4;
+      const int sw = swz(row);
+      drow[(pc4_) ^ sw] = o_i;
+      drow[(LPR + pc4_) ^ sw] = o_j;
+      drow[(2 * LPR + pc4_) ^ sw] = o_f;
+      drow[(3 * LPR + pc4_) ^ sw] = o_o;
+      dbs[0][0] += o_i.x, dbs[0][1] += o_i.y, dbs[0][2] += o_i.z, dbs[0][3] += o_i.w;
+      dbs[1][0] += o_j.x, dbs[1][1] += o_j.y, dbs[1][2] += o_j.z, dbs[1][3] += o_j.w;
+      dbs[2][0] += o_f.x, dbs[2][1] += o_f.y, dbs[2][2] += o_f.z, dbs[2][3] += o_f.w;
+      dbs[3][0] += o_o.x, dbs[3][1] += o_o.y, dbs[3][2] += o_o.z, dbs[3][3] += o_o.w;
+    }
+    __syncthreads();  // dG complete; dhr consumed
+
+    // ---- global operands: A of MFMA 2 (my 32 columns of [x_t | h_{t-1}], rows 2kk + kh), used after
+    // MFMA 1; then the next item's phase-A operands, in flight under both MFMA phases ---------------
+    const bool do_w = !h_side || ts > 0;  // h_{-1} = 0 contributes nothing
+    float a2[16];
+    {
+      const float* src = h_side ? h + (int64_t)(ts > 0 ? ts - 1 : 0) * D + 32 * (ta - XT) + li_
+                                : x + (int64_t)ts * ld_t + 32 * ta + li_;
+      const int64_t ldr = h_side ? (int64_t)t * D : ld_n;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int64_t grow = row0 + 2 * kk + kh_;
+        const float v = src[(grow < n ? grow : n - 1) * ldr];  // clamped: no branch around the load
+        a2[kk] = (grow < n && do_w) ? v : 0.f;
+      }
+    }
+    if (nch < n_chunks) prefetch(nch * kRows, nts);
+
+    // ---- MFMA 1: d[x_t | h_{t-1}][:, 32ta .. 32ta+31] = dG @ W^T ---------------------------------
+    if (mfma1_wave && (!h_side || ts > 0)) {
+      f32x16 c0, c1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c0[r] = 0.f, c1[r] = 0.f;
+      const float4* arow = reinterpret_cast<const float4*>(dg) + li_ * S4;
+      const float4* wq = wl + wave * QL * 64 + lane;
+      const int sw = swz(li_);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float4 a = arow[(2 * q + kh_) ^ sw];
+        float4 w;
+        if (q < QR) w = make_float4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
+        else w = wq[(q - QR) * 64];
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, c1, 0, 0, 0);
+      }
+      if (!h_side) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t grow = row0 + crow(r, kh_);
+          if (grow < n) dx[(grow * t + ts) * D + 32 * ta + li_] = c0[r] + c1[r];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dhr[crow(r, kh_) * D + 32 * (ta - XT) + li_] = c0[r] + c1[r];
+      }
+    }
+
+    // ---- MFMA 2: dW[32ta .. , :] += [x_t | h_{t-1}]^T dG (unconditional: a branch around it makes
+    // the compiler keep two copies of the 128 accumulators; the h-side waves multiply zeros at ts = 0)
+    {
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const int row = 2 * kk + kh_;
+        const float* brow = dg + row * NC + (li_ & 3);
+        const int sw = swz(row);
+#pragma unroll
+        for (int j = 0; j < NTB; ++j) {
+          const int tb = tb0 + j * WPT;
+          const float b = brow[((tb * 8 + (li_ >> 2)) ^ sw) * 4];
+          accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk], b, accw[j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // dG consumed, dhr written
+    ch = nch;
+    ts = nts;
+  }
+
+  // ---- flush: dW tiles with float atomics, db through an LDS reduction over the row groups ------
+#pragma unroll
+  for (int j = 0; j < NTB; ++j) {
+    const int tb = tb0 + j * WPT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      atomicAdd(dW + (size_t)(32 * ta + crow(r, kh)) * NC + 32 * tb + li, accw[j][r]);
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dg[prow * NC + g * D + 4 * pc4 + e] = dbs[g][e];
+  __syncthreads();
+  if (tid < NC) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < RPP; ++r) s += dg[r * NC + tid];
+    atomicAdd(db + tid, s);
+  }
+}
+
+int cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, v = 0;
+    cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      cus = v;
+  }
+  return cus;
+}
+
+template <int D>
+int launch(const float* x, int64_t ld_n, int64_t ld_t, const float* h, const float* gates, const float* cell,
+           const float* dh_ext, int64_t ld_dhe, const float* drop, const float* W, float* dx, float* dW, float* db,
+           int64_t n, int t, hipStream_t s) {
+  const int64_t n_chunks = (n + kRows - 1) / kRows;
+  const int64_t blocks = n_chunks < cu_count() ? n_chunks : cu_count();
+  const int nq = 4 * D / 8, ql = nq - (D == 64 ? 2 : 0), nw1 = 2 * D / 32;
+  const size_t lds = (size_t)kRows * (4 * D + D) * sizeof(float) + (size_t)nw1 * ql * 64 * sizeof(float4);
+  static bool configured = false;
+  if (!configured) {
+    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_mfma_kernel<D>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  hipLaunchKernelGGL(lstm_bwd_mfma_kernel<D>, dim3((unsigned)blocks), dim3(kBlock), lds, s, x, ld_n, ld_t, h, gates,
+                     cell, dh_ext, ld_dhe, drop, W, dx, dW, db, n, t, n_chunks);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+}  // namespace
+
+extern "C" int sagnn_lstm_bwd_supported(int d) { return d == 32 || d == 64; }
+
+extern "C" int sagnn_lstm_bwd_f32(const float* x, int64_t ld_n, int64_t ld_t, const float* h, const float* gates,
+                                  const float* cell, const float* dh_ext, int64_t ld_dhe, const float* drop_scale,
+                                  const float* W, float* dx, float* dW, float* db, int64_t n, int t, int d,
+                                  void* stream) {
+  if (n < 0 || t < 1) return sagnn::fail(SAGNN_ERR_DIM, "bad n/t");
+  if (!sagnn_lstm_bwd_supported(d)) return sagnn::fail(SAGNN_ERR_DIM, "lstm_bwd: d must be 32 or 64 (got %d)", d);
+  if (!x || !h || !gates || !cell || !dh_ext || !W || !dx || !dW || !db)
+    return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (ld_n < d || (t > 1 && ld_t < d) || ld_dhe < (int64_t)t * d)
+    return sagnn::fail(SAGNN_ERR_ARG, "strides smaller than the rows they address");
+  if ((ld_dhe & 3) || !sagnn::aligned16(dh_ext) || !sagnn::aligned16(gates) || !sagnn::aligned16(cell) ||
+      !sagnn::aligned16(W) || (drop_scale && !sagnn::aligned16(drop_scale)))
+    return sagnn::fail(SAGNN_ERR_ALIGN, "lstm_bwd: need 16-byte aligned rows");
+  if (n == 0) return SAGNN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (d == 64) return launch<64>(x, ld_n, ld_t, h, gates, cell, dh_ext, ld_dhe, drop_scale, W, dx, dW, db, n, t, s);
+  return launch<32>(x, ld_n, ld_t, h, gates, cell, dh_ext, ld_dhe, drop_scale, W, dx, dW, db, n, t, s);
+}

@@ -131,6 +131,29 @@ def test_interval_fusion_backward_with_output_dropout(dev):
         assert (np.abs(a - b) <= tol).all(), name
 
 
+@pytest.mark.parametrize("d,t,n", [(64, 4, 20011), (32, 3, 33000)])
+def test_fused_bptt_matches_step_loop(dev, d, t, n, monkeypatch):
+    """sagnn_lstm_bwd_f32 (one launch, gate gradients on chip) against the per-step entries it
+    replaces, at sizes where every block walks several chunks and the last chunk is ragged."""
+    from sa_gnn_amd import autograd as ag
+    rng = np.random.default_rng(d * t)
+    p = O.init_fusion_params(d, rng)
+    x = torch.from_numpy(rng.standard_normal((n, t, d)).astype(np.float32)).to(dev)
+    gout = torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(dev)
+    scale = torch.from_numpy(((rng.random((n, t, d)) < 0.7) / 0.7).astype(np.float32)).to(dev)
+    grads = {}
+    for mode in ("fused", "steps"):
+        monkeypatch.setenv("SAGNN_BPTT", mode)
+        xd = x.clone().requires_grad_(True)
+        pd = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in p.items()}
+        ag.interval_fusion(xd, pd, 16, drop_scale=scale).backward(gout)
+        grads[mode] = {"x": xd.grad, **{k: pd[k].grad for k in ("lstm_W", "lstm_b")}}
+    for k in grads["fused"]:
+        a, b = grads["fused"][k].double().cpu().numpy(), grads["steps"][k].double().cpu().numpy()
+        tol = 1e-4 * np.abs(b) + 2e-5 * np.abs(b).max()
+        assert (np.abs(a - b) <= tol).all(), f"{k}: worst {np.abs(a - b).max():.3e} (scale {np.abs(b).max():.3e})"
+
+
 def test_adam_step_matches_tf_formula(dev):
     from sa_gnn_amd import ops
     rng = np.random.default_rng(1)
