@@ -251,6 +251,15 @@ int sagnn_mhsa_mean_wide_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t
                              const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv,
                              const float* bv, float* out, int64_t ld_out, void* workspace, size_t workspace_bytes,
                              void* stream);
+/* layer_norm over (T, d) + attention + mean without the LSTM (model.py:152-155): what the
+ * training forward calls after sagnn_lstm_fwd_train_f32. Workspace (bytes from
+ * sagnn_ln_mhsa_mean_workspace_bytes, 0 on the fused matrix-core path) holds the normalised
+ * tensor where the normalisation cannot ride on the attention kernel's operand. */
+size_t sagnn_ln_mhsa_mean_workspace_bytes(int64_t n, int t, int d, int heads);
+int sagnn_ln_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
+                           const float* ln_gamma, const float* ln_beta, float ln_eps, const float* Wq,
+                           const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
+                           float* out, int64_t ld_out, void* workspace, size_t workspace_bytes, void* stream);
 int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
                               const float* lstm_W, const float* lstm_b, float forget_bias,
                               const float* ln_gamma, const float* ln_beta, float ln_eps,

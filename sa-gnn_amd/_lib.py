@@ -66,6 +66,10 @@ SIGNATURES = {
     "sagnn_lstm_fwd_train_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_float,
                                          c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "sagnn_mhsa_wide_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "sagnn_ln_mhsa_mean_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "sagnn_ln_mhsa_mean_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
+                                       c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int64, c_void_p, c_size_t, c_void_p]),
     "sagnn_mhsa_mean_wide_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_size_t,
                                          c_void_p]),

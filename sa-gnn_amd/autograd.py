@@ -99,8 +99,8 @@ class IntervalFusionFn(torch.autograd.Function):
             ops._vec("lstm_b", lstm_b.detach(), 4 * d), 1.0, None, h.data_ptr(), t * d,
             gates.data_ptr(), cell.data_ptr(), ops._stream()))
         h_emit = h if drop_scale is None else ops.mul(h, drop_scale.contiguous())
-        y = ops.layernorm_td(h_emit, ln_gamma.detach(), ln_beta.detach())
-        out = ops.mhsa_mean(y, Wq.detach(), bq.detach(), Wk.detach(), bk.detach(), Wv.detach(), bv.detach(), heads)
+        out = ops.ln_mhsa_mean(h_emit, ln_gamma.detach(), ln_beta.detach(), Wq.detach(), bq.detach(), Wk.detach(),
+                               bk.detach(), Wv.detach(), bv.detach(), heads)
         ctx.save_for_backward(x, lstm_W, ln_gamma, ln_beta, Wq, bq, Wk, bk, Wv, bv, h, gates, cell,
                               drop_scale if drop_scale is not None else torch.empty(0, device=dev))
         ctx.heads = heads

@@ -126,68 +126,123 @@ __global__ __launch_bounds__(kBlock, 1) void dense_nn_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// tn: the block walks 32-row chunks; X and G chunks sit row-major in LDS; the (DIN/32)x(DOUT/32)
-// output tiles are dealt to the 4 waves (TPW each), accumulated over every chunk of the block and
-// flushed once with float atomics (<= a few MB per launch). Column sums of G (bias gradient)
-// ride along, one column per thread.
+// tn: the block walks RC-row chunks; X and G chunks sit row-major in a DOUBLE-BUFFERED LDS tile
+// (the next chunk is in flight in registers while the MFMAs of the current one run; one barrier
+// per chunk); the (DIN/32)x(DOUT/32) output tiles are dealt to the 4 waves (TPW each), accumulated
+// over every chunk of the block and flushed once with float atomics (<= a few MB per launch).
+// Column sums of G (bias gradient) ride along, one column per thread.
 // ---------------------------------------------------------------------------------------------
-template <int TPW>
+template <int TPW, int RC, int NV>
 __global__ __launch_bounds__(kBlock, 1) void dense_tn_kernel(const float* __restrict__ X, int64_t ldx,
                                                              const float* __restrict__ G, int64_t ldg,
                                                              int64_t n, int din, int dout,
                                                              float* __restrict__ dW, int64_t lddw,
                                                              float* __restrict__ db, int64_t n_chunks) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xs = lds;                    // [32][din]
-  float* gs = lds + 32 * din;         // [32][dout]
+  const int width = din + dout;       // one LDS row: X part | G part
+  const int tile = RC * width;        // floats per buffer
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int li = lane & 31, kh = lane >> 5;
   const int nb = dout / 32;
   const int n_out_tiles = (din / 32) * nb;
+  const int w4 = width / 4;           // float4 per row
+  const int nvec = RC * w4;           // float4 per chunk (<= NV * kBlock)
   f32x16 acc[TPW];
 #pragma unroll
   for (int j = 0; j < TPW; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   float colsum = 0.f;
+  int aoff[TPW], boff[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    int tt = wave * TPW + j;
+    if (tt >= n_out_tiles) tt = n_out_tiles - 1;
+    const int ta = tt / nb, tb = tt - ta * nb;
+    aoff[j] = ta * 32 + li;
+    boff[j] = tb * 32 + li;
+  }
 
-  for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-    const int64_t row0 = ch * 32;
-    __syncthreads();  // previous chunk fully consumed
-    for (int i = threadIdx.x * 4; i < 32 * din; i += blockDim.x * 4) {
-      const int r = i / din, c = i - r * din;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + r < n) v = *reinterpret_cast<const float4*>(X + (row0 + r) * ldx + c);
-      *reinterpret_cast<float4*>(xs + i) = v;
+  float4 stage[NV];
+  auto fetch = [&](int64_t ch) {
+    const int64_t row0 = ch * RC;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int i = threadIdx.x + v * kBlock;
+      const int r = i / w4, c = (i - r * w4) * 4;
+      // branch-free: out-of-range slots read a clamped address and are zeroed by a select
+      const bool ok = i < nvec && row0 + r < n;
+      const int64_t gr = row0 + r < n ? row0 + r : n - 1;
+      const int rr = i < nvec ? c : 0;
+      const float* src = rr < din ? X + gr * ldx + rr : G + gr * ldg + (rr - din);
+      const float4 val = *reinterpret_cast<const float4*>(src);
+      stage[v] = make_float4(ok ? val.x : 0.f, ok ? val.y : 0.f, ok ? val.z : 0.f, ok ? val.w : 0.f);
     }
-    for (int i = threadIdx.x * 4; i < 32 * dout; i += blockDim.x * 4) {
-      const int r = i / dout, c = i - r * dout;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + r < n) v = *reinterpret_cast<const float4*>(G + (row0 + r) * ldg + c);
-      *reinterpret_cast<float4*>(gs + i) = v;
+  };
+  auto commit = [&](float* buf) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int i = threadIdx.x + v * kBlock;
+      if (i < nvec) reinterpret_cast<float4*>(buf)[i] = stage[v];
     }
-    __syncthreads();
+  };
+
+  int64_t ch = blockIdx.x;
+  int cur = 0;
+  if (ch < n_chunks) {
+    fetch(ch);
+    commit(lds);
+  }
+  __syncthreads();
+  for (; ch < n_chunks; ch += gridDim.x) {
+    const int64_t nxt = ch + gridDim.x;
+    if (nxt < n_chunks) fetch(nxt);  // lands under the MFMAs below
+    const float* xs = lds + cur * tile;
+    const float* gs = xs + din;
     if (db && (int)threadIdx.x < dout) {
       float s = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < 32; ++r) s += gs[r * dout + threadIdx.x];
+      for (int r = 0; r < RC; ++r) s += gs[r * width + threadIdx.x];
       colsum += s;
     }
+    // No validity branch in here: a wave whose tile index runs past the last tile recomputes the
+    // last one and drops it at the flush (a branch per MFMA would fence every LDS read). Operands
+    // are read one GROUP of k-steps ahead of the MFMAs that use them: one MFMA (64 cycles) does
+    // not cover an LDS round trip, so reading "just in time" halves the matrix-core rate.
+    {
+      constexpr int GK = TPW >= 4 ? 2 : 4;  // k-steps per group: 2*GK*TPW operand registers, twice
+      constexpr int NG = RC / 2 / GK;
+      float ac[GK][TPW], bc[GK][TPW], an[GK][TPW], bn[GK][TPW];
+      auto read_group = [&](float (&a)[GK][TPW], float (&b)[GK][TPW], int g) {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      const int row = 2 * kk + kh;
+        for (int u = 0; u < GK; ++u) {
+          const int row = 2 * (g * GK + u) + kh;
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        const int tt = wave * TPW + j;
-        if (tt < n_out_tiles) {  // wave-uniform
-          const int ta = tt / nb, tb = tt - ta * nb;
-          const float av = xs[row * din + ta * 32 + li];   // A[i = din index][k = row]
-          const float bv = gs[row * dout + tb * 32 + li];  // B[k = row][j = dout index]
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+          for (int j = 0; j < TPW; ++j) {
+            a[u][j] = xs[row * width + aoff[j]];  // A[i = din index][k = row]
+            b[u][j] = gs[row * width + boff[j]];  // B[k = row][j = dout index]
+          }
         }
+      };
+      read_group(ac, bc, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) read_group(an, bn, g + 1);
+#pragma unroll
+        for (int u = 0; u < GK; ++u)
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[u][j], bc[u][j], acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < GK; ++u)
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) ac[u][j] = an[u][j], bc[u][j] = bn[u][j];
       }
     }
+    if (nxt < n_chunks) commit(lds + (cur ^ 1) * tile);
+    __syncthreads();  // next buffer complete; this one free to be overwritten next time round
+    cur ^= 1;
   }
 #pragma unroll
   for (int j = 0; j < TPW; ++j) {
@@ -233,22 +288,32 @@ int launch_nn(const float* X, int64_t ldx, int64_t n, int din, const float* W, i
   return SAGNN_OK;
 }
 
-template <int TPW>
-int launch_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW,
-              int64_t lddw, float* db, hipStream_t s) {
-  const size_t lds = (size_t)32 * (din + dout) * sizeof(float);
+template <int TPW, int RC, int NV>
+int launch_tn_rc(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW,
+                 int64_t lddw, float* db, hipStream_t s) {
+  const size_t lds = (size_t)2 * RC * (din + dout) * sizeof(float);
   static size_t configured = 0;
   if (lds > configured) {
-    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_tn_kernel<TPW>),
+    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_tn_kernel<TPW, RC, NV>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = lds;
   }
-  const int64_t n_chunks = (n + 31) / 32;
+  const int64_t n_chunks = (n + RC - 1) / RC;
   const int64_t blocks = n_chunks < cu_count() ? n_chunks : cu_count();
-  hipLaunchKernelGGL(dense_tn_kernel<TPW>, dim3((unsigned)blocks), dim3(kBlock), lds, s, X, ldx, G, ldg, n, din,
-                     dout, dW, lddw, db, n_chunks);
+  hipLaunchKernelGGL((dense_tn_kernel<TPW, RC, NV>), dim3((unsigned)blocks), dim3(kBlock), lds, s, X, ldx, G, ldg, n,
+                     din, dout, dW, lddw, db, n_chunks);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
+}
+
+// din + dout <= 384 (dense_tn_any slices to 128 x 256). 64-row chunks while both buffers fit LDS
+// and the staging registers stay at 16 float4 per thread.
+template <int TPW>
+int launch_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW,
+              int64_t lddw, float* db, hipStream_t s) {
+  const int width = din + dout;
+  if (width <= 256) return launch_tn_rc<TPW, 64, 16>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
+  return launch_tn_rc<TPW, 32, 12>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
 }
 
 int check_xy(const char* name, const void* p, int64_t ld, int cols) {
@@ -285,7 +350,7 @@ int tn_piece(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n
   if (tpw <= 3) return launch_tn<3>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
   if (tpw <= 4) return launch_tn<4>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
   if (tpw <= 8) return launch_tn<8>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
-  return launch_tn<16>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
+  return sagnn::fail(SAGNN_ERR_DIM, "dense_tn piece %d x %d exceeds 128 x 256", din, dout);  // dense_tn_any slices
 }
 
 constexpr int kLdsFloatsForW = (160 * 1024 - 4 * 32 * 32 * 4) / 4;  // what dense_nn can give to W

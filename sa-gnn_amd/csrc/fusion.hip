@@ -446,6 +446,45 @@ extern "C" int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t l
 }
 
 
+// layer_norm over (T, d) + attention + mean (model.py:152-155) without the LSTM: the training
+// forward runs the LSTM separately (it stores gates / cell) and comes here with the emitted h.
+extern "C" size_t sagnn_ln_mhsa_mean_workspace_bytes(int64_t n, int t, int d, int heads) {
+  if (n <= 0 || t <= 0 || d <= 0) return 0;
+  if (sagnn::mhsa_mfma_supported(d, t, heads) && !sagnn::force_valu()) return 0;  // normalised in registers
+  size_t bytes = (size_t)n * (size_t)t * (size_t)d * sizeof(float);
+  if (use_wide(d)) bytes += sagnn_mhsa_wide_workspace_bytes(n, t, d);
+  return bytes;
+}
+
+extern "C" int sagnn_ln_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
+                                      const float* ln_gamma, const float* ln_beta, float ln_eps, const float* Wq,
+                                      const float* bq, const float* Wk, const float* bk, const float* Wv,
+                                      const float* bv, float* out, int64_t ld_out, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+  if (int rc = check_dims(n, t, d)) return rc;
+  if (heads < 1 || d % heads) return sagnn::fail(SAGNN_ERR_DIM, "heads = %d does not divide d = %d", heads, d);
+  if (!x || !ln_gamma || !ln_beta || !Wq || !bq || !Wk || !bk || !Wv || !bv || !out)
+    return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (int rc = check_strides(ld_n, ld_t, n, t, d)) return rc;
+  if (ld_out < d) return sagnn::fail(SAGNN_ERR_ARG, "ld_out smaller than d");
+  if (n == 0) return SAGNN_OK;
+  const bool vec_ok = sagnn::aligned16(x) && (ld_n & 3) == 0 && (ld_t & 3) == 0;
+  if (sagnn::mhsa_mfma_supported(d, t, heads) && vec_ok && !sagnn::force_valu())
+    return sagnn::ln_mhsa_mean_mfma(x, ld_n, ld_t, n, t, d, heads, ln_gamma, ln_beta, ln_eps, 1, Wq, bq, Wk, bk,
+                                    Wv, bv, out, ld_out, static_cast<hipStream_t>(stream));
+  const size_t ybytes = (size_t)n * t * d * sizeof(float);
+  size_t need = ybytes + (use_wide(d) ? sagnn_mhsa_wide_workspace_bytes(n, t, d) : 0);
+  if (!workspace || workspace_bytes < need)
+    return sagnn::fail(SAGNN_ERR_WORKSPACE, "ln_mhsa_mean workspace needs %zu bytes", need);
+  float* y = static_cast<float*>(workspace);
+  const int64_t ldw = (int64_t)t * d;
+  if (int rc = sagnn_layernorm_td_f32(x, ld_n, ld_t, n, t, d, ln_gamma, ln_beta, ln_eps, y, ldw, stream)) return rc;
+  if (use_wide(d))
+    return sagnn_mhsa_mean_wide_f32(y, ldw, d, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out, y + n * ldw,
+                                    workspace_bytes - ybytes, stream);
+  return sagnn_mhsa_mean_f32(y, ldw, d, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out, stream);
+}
+
 extern "C" int sagnn_lstm_fwd_train_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
                                         const float* W, const float* b, float forget_bias,
                                         const float* drop_scale, float* h, int64_t ld_h, float* gates,

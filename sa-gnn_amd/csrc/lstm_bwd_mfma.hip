@@ -237,17 +237,34 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
     // ---- MFMA 2: dW[32ta .. , :] += [x_t | h_{t-1}]^T dG (unconditional: a branch around it makes
     // the compiler keep two copies of the 128 accumulators; the h-side waves multiply zeros at ts = 0)
     {
+      // B operands are read one group of k-steps ahead (an MFMA does not cover an LDS round trip)
+      constexpr int GK = NTB >= 8 ? 2 : 4;
+      constexpr int NG = 16 / GK;
+      float bc[GK][NTB], bn[GK][NTB];
+      auto read_group = [&](float (&b)[GK][NTB], int g) {
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int row = 2 * kk + kh_;
-        const float* brow = dg + row * NC + (li_ & 3);
-        const int sw = swz(row);
+        for (int u = 0; u < GK; ++u) {
+          const int row = 2 * (g * GK + u) + kh_;
+          const float* brow = dg + row * NC + (li_ & 3);
+          const int sw = swz(row);
 #pragma unroll
-        for (int j = 0; j < NTB; ++j) {
-          const int tb = tb0 + j * WPT;
-          const float b = brow[((tb * 8 + (li_ >> 2)) ^ sw) * 4];
-          accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[kk], b, accw[j], 0, 0, 0);
+          for (int j = 0; j < NTB; ++j) b[u][j] = brow[(((tb0 + j * WPT) * 8 + (li_ >> 2)) ^ sw) * 4];
         }
+      };
+      read_group(bc, 0);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) read_group(bn, g + 1);
+#pragma unroll
+        for (int u = 0; u < GK; ++u)
+#pragma unroll
+          for (int j = 0; j < NTB; ++j)
+            accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[g * GK + u], bc[u][j], accw[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < GK; ++u)
+#pragma unroll
+          for (int j = 0; j < NTB; ++j) bc[u][j] = bn[u][j];
       }
     }
     __syncthreads();  // dG consumed, dhr written

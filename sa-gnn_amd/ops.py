@@ -291,6 +291,21 @@ def mhsa_mean(x: torch.Tensor, Wq, bq, Wk, bk, Wv, bv, heads: int, out: torch.Te
     return out
 
 
+def ln_mhsa_mean(x: torch.Tensor, gamma, beta, Wq, bq, Wk, bk, Wv, bv, heads: int, eps: float = 1e-12):
+    """layer_norm over (T, d) -> MHSA -> mean (reference model.py:152-155) in one call:
+    sagnn_ln_mhsa_mean_f32 (fused on the matrix-core path). x [n, t, d] -> [n, d]."""
+    n, t, d, ld, ldt = _ntd("x", x)
+    out = torch.empty((n, d), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    need = int(lib.sagnn_ln_mhsa_mean_workspace_bytes(n, t, d, int(heads)))
+    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device) if need else None
+    check(lib.sagnn_ln_mhsa_mean_f32(
+        x.data_ptr(), ld, ldt, n, t, d, int(heads), _vec("gamma", gamma, d), _vec("beta", beta, d), float(eps),
+        _vec("Wq", Wq, d * d), _vec("bq", bq, d), _vec("Wk", Wk, d * d), _vec("bk", bk, d), _vec("Wv", Wv, d * d),
+        _vec("bv", bv, d), out.data_ptr(), d, _ptr(ws), need, _stream()))
+    return out
+
+
 def interval_fusion(x: torch.Tensor, p: dict, heads: int, out: torch.Tensor | None = None,
                     workspace: torch.Tensor | None = None):
     """LSTM -> layer_norm -> MHSA -> mean (reference model.py:135-155): sagnn_interval_fusion_f32.
