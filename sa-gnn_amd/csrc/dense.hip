@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock, 1) void dense_nn_kernel(const float* __rest
 // Column sums of G (bias gradient) ride along, one column per thread.
 // ---------------------------------------------------------------------------------------------
 template <int TPW, int RC, int NV>
-__global__ __launch_bounds__(kBlock, 1) void dense_tn_kernel(const float* __restrict__ X, int64_t ldx,
+__global__ __launch_bounds__(kBlock, TPW <= 4 ? 2 : 1) void dense_tn_kernel(const float* __restrict__ X, int64_t ldx,
                                                              const float* __restrict__ G, int64_t ldg,
                                                              int64_t n, int din, int dout,
                                                              float* __restrict__ dW, int64_t lddw,
@@ -299,20 +299,19 @@ int launch_tn_rc(const float* X, int64_t ldx, const float* G, int64_t ldg, int64
     configured = lds;
   }
   const int64_t n_chunks = (n + RC - 1) / RC;
-  const int64_t blocks = n_chunks < cu_count() ? n_chunks : cu_count();
+  const int64_t want = (int64_t)cu_count() * ((TPW <= 4 && lds <= 72 * 1024) ? 2 : 1);
+  const int64_t blocks = n_chunks < want ? n_chunks : want;
   hipLaunchKernelGGL((dense_tn_kernel<TPW, RC, NV>), dim3((unsigned)blocks), dim3(kBlock), lds, s, X, ldx, G, ldg, n,
                      din, dout, dW, lddw, db, n_chunks);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
 
-// din + dout <= 384 (dense_tn_any slices to 128 x 256). 64-row chunks while both buffers fit LDS
-// and the staging registers stay at 16 float4 per thread.
+// din + dout <= 384 (dense_tn_any slices to 128 x 256): 32-row chunks, two buffers <= 96 KB. With
+// <= 4 tiles per wave two blocks share a CU (their chunks' loads and MFMAs interleave).
 template <int TPW>
 int launch_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW,
               int64_t lddw, float* db, hipStream_t s) {
-  const int width = din + dout;
-  if (width <= 256) return launch_tn_rc<TPW, 64, 16>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
   return launch_tn_rc<TPW, 32, 12>(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);
 }
 

@@ -15,6 +15,34 @@
 // never leaves the CU. Global operands of the next step are requested before the MFMAs.
 #include "common.h"
 
+// Diagnostic build only (-DSAGNN_STAMPS): per-section cycle sums, read with sagnn_debug_read_stamps_bwd().
+#ifdef SAGNN_STAMPS
+__device__ unsigned long long g_bwd_stamps[8];
+__device__ __forceinline__ unsigned long long bwd_stamp_now() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define BSTAMP_DECL unsigned long long st_prev = bwd_stamp_now(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define BSTAMP(i)                                   \
+  do {                                              \
+    const unsigned long long _t = bwd_stamp_now();  \
+    st_acc[i] += _t - st_prev;                      \
+    st_prev = _t;                                   \
+  } while (0)
+#define BSTAMP_FLUSH                                                           \
+  do {                                                                         \
+    if ((threadIdx.x & 63) == 0)                                               \
+      for (int _i = 0; _i < 8; ++_i) atomicAdd(&g_bwd_stamps[_i], st_acc[_i]); \
+  } while (0)
+#else
+#define BSTAMP_DECL
+#define BSTAMP(i)
+#define BSTAMP_FLUSH
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -68,6 +96,18 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
   // W[32ta+li][8q+4kh .. +3], i.e. the B operands of MFMAs 4q .. 4q+3 (k order matches the b128
   // A reads of the dG tile)
   float wb[QR > 0 ? 4 * QR : 1];
+  float wbp[QR > 0 ? 4 * QR : 1];  // h-side waves: the register fragments of x tile ta - XT (see MFMA 1)
+  if (mfma1_wave && h_side) {
+    const float* prow = W + (size_t)(32 * (ta - XT) + li) * NC + 4 * kh;
+#pragma unroll
+    for (int q = 0; q < QR; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(prow + 8 * q);
+      wbp[4 * q + 0] = v.x;
+      wbp[4 * q + 1] = v.y;
+      wbp[4 * q + 2] = v.z;
+      wbp[4 * q + 3] = v.w;
+    }
+  }
   if (mfma1_wave) {
     const float* wrow = W + (size_t)(32 * ta + li) * NC + 4 * kh;
 #pragma unroll
@@ -83,8 +123,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
       }
     }
   }
-  // (each wave reads back only what it wrote: no block barrier needed before the first MFMA 1,
-  // and the loop's own barriers come first anyway)
+  // (read back after the loop's first barrier)
 
   f32x16 accw[NTB];
 #pragma unroll
@@ -127,6 +166,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
   int64_t ch = blockIdx.x;
   int ts = t - 1;
   if (ch < n_chunks) prefetch(ch * kRows, ts);
+  BSTAMP_DECL;
   while (ch < n_chunks) {
     const int64_t row0 = ch * kRows;
     const int64_t nch = ts > 0 ? ch : ch + gridDim.x;
@@ -184,7 +224,9 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
       dbs[2][0] += o_f.x, dbs[2][1] += o_f.y, dbs[2][2] += o_f.z, dbs[2][3] += o_f.w;
       dbs[3][0] += o_o.x, dbs[3][1] += o_o.y, dbs[3][2] += o_o.z, dbs[3][3] += o_o.w;
     }
+    BSTAMP(0);
     __syncthreads();  // dG complete; dhr consumed
+    BSTAMP(1);
 
     // ---- global operands: A of MFMA 2 (my 32 columns of [x_t | h_{t-1}], rows 2kk + kh), used after
     // MFMA 1; then the next item's phase-A operands, in flight under both MFMA phases ---------------
@@ -202,40 +244,51 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
       }
     }
     if (nch < n_chunks) prefetch(nch * kRows, nts);
+    BSTAMP(2);
 
-    // ---- MFMA 1: d[x_t | h_{t-1}][:, 32ta .. 32ta+31] = dG @ W^T ---------------------------------
-    if (mfma1_wave && (!h_side || ts > 0)) {
+    // ---- MFMA 1: one 32-column tile of d[x_t | h_{t-1}] = dG @ W^T per wave. For ts > 0 wave w
+    // takes tile w. At ts = 0 only dx is needed and the x-side waves still have their MFMA 2 to do,
+    // so the otherwise idle h-side waves compute the dx tiles (the step then costs every wave 4D/2
+    // MFMAs instead of 4D for half of them).
+    const int m1 = ts > 0 ? ta : (h_side ? ta - XT : -1);
+    if (mfma1_wave && m1 >= 0) {
       f32x16 c0, c1;
 #pragma unroll
       for (int r = 0; r < 16; ++r) c0[r] = 0.f, c1[r] = 0.f;
       const float4* arow = reinterpret_cast<const float4*>(dg) + li_ * S4;
-      const float4* wq = wl + wave * QL * 64 + lane;
+      const float4* wq = wl + m1 * QL * 64 + lane;
+      const bool own = m1 == ta;
       const int sw = swz(li_);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const float4 a = arow[(2 * q + kh_) ^ sw];
         float4 w;
-        if (q < QR) w = make_float4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
-        else w = wq[(q - QR) * 64];
+        if (q < QR)
+          w = make_float4(own ? wb[4 * q] : wbp[4 * q], own ? wb[4 * q + 1] : wbp[4 * q + 1],
+                          own ? wb[4 * q + 2] : wbp[4 * q + 2], own ? wb[4 * q + 3] : wbp[4 * q + 3]);
+        else
+          w = wq[(q - QR) * 64];
         c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, c1, 0, 0, 0);
         c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, c1, 0, 0, 0);
       }
-      if (!h_side) {
+      if (m1 < XT) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t grow = row0 + crow(r, kh_);
-          if (grow < n) dx[(grow * t + ts) * D + 32 * ta + li_] = c0[r] + c1[r];
+          if (grow < n) dx[(grow * t + ts) * D + 32 * m1 + li_] = c0[r] + c1[r];
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dhr[crow(r, kh_) * D + 32 * (ta - XT) + li_] = c0[r] + c1[r];
+        for (int r = 0; r < 16; ++r) dhr[crow(r, kh_) * D + 32 * (m1 - XT) + li_] = c0[r] + c1[r];
       }
     }
 
-    // ---- MFMA 2: dW[32ta .. , :] += [x_t | h_{t-1}]^T dG (unconditional: a branch around it makes
-    // the compiler keep two copies of the 128 accumulators; the h-side waves multiply zeros at ts = 0)
+    BSTAMP(3);
+    // ---- MFMA 2: dW[32ta .. , :] += [x_t | h_{t-1}]^T dG. h_{-1} = 0: nothing to do for the h side at
+    // ts = 0 — expressed as a zero trip count of a rolled loop, not as a branch around the block (with
+    // a branch the compiler keeps two copies of the 128 accumulators and spills).
     {
       // B operands are read one group of k-steps ahead (an MFMA does not cover an LDS round trip)
       constexpr int GK = NTB >= 8 ? 2 : 4;
@@ -251,15 +304,22 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
           for (int j = 0; j < NTB; ++j) b[u][j] = brow[(((tb0 + j * WPT) * 8 + (li_ >> 2)) ^ sw) * 4];
         }
       };
+      const int ng = do_w ? NG : 0;
       read_group(bc, 0);
+#pragma unroll 1
+      for (int g = 0; g < ng; ++g) {
+        read_group(bn, g + 1 < NG ? g + 1 : g);
+        float av[GK];
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) read_group(bn, g + 1);
+        for (int u = 0; u < GK; ++u) {
+          av[u] = a2[0];
+#pragma unroll
+          for (int k = 1; k < 16; ++k) av[u] = (g * GK + u == k) ? a2[k] : av[u];  // register select, no scratch
+        }
 #pragma unroll
         for (int u = 0; u < GK; ++u)
 #pragma unroll
-          for (int j = 0; j < NTB; ++j)
-            accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[g * GK + u], bc[u][j], accw[j], 0, 0, 0);
+          for (int j = 0; j < NTB; ++j) accw[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bc[u][j], accw[j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < GK; ++u)
@@ -267,11 +327,14 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
           for (int j = 0; j < NTB; ++j) bc[u][j] = bn[u][j];
       }
     }
+    BSTAMP(4);
     __syncthreads();  // dG consumed, dhr written
+    BSTAMP(5);
     ch = nch;
     ts = nts;
   }
 
+  BSTAMP_FLUSH;
   // ---- flush: dW tiles with float atomics, db through an LDS reduction over the row groups ------
 #pragma unroll
   for (int j = 0; j < NTB; ++j) {
@@ -347,3 +410,14 @@ extern "C" int sagnn_lstm_bwd_f32(const float* x, int64_t ld_n, int64_t ld_t, co
   if (d == 64) return launch<64>(x, ld_n, ld_t, h, gates, cell, dh_ext, ld_dhe, drop_scale, W, dx, dW, db, n, t, s);
   return launch<32>(x, ld_n, ld_t, h, gates, cell, dh_ext, ld_dhe, drop_scale, W, dx, dW, db, n, t, s);
 }
+
+#ifdef SAGNN_STAMPS
+extern "C" int sagnn_debug_read_stamps_bwd(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwd_stamps), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_stamps), z, sizeof z) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
