@@ -25,7 +25,14 @@ __device__ __forceinline__ unsigned long long bwd_stamp_now() {
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
-#define BSTAMP_DECL unsigned long long st_prev = bwd_stamp_now(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+__device__ __forceinline__ unsigned long long bwd_realtime_now() {  // constant 100 MHz
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define BSTAMP_DECL                                                                      \
+  unsigned long long st_prev = bwd_stamp_now(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};  \
+  const unsigned long long st_t0 = st_prev, st_r0 = bwd_realtime_now()
 #define BSTAMP(i)                                   \
   do {                                              \
     const unsigned long long _t = bwd_stamp_now();  \
@@ -34,6 +41,10 @@ __device__ __forceinline__ unsigned long long bwd_stamp_now() {
   } while (0)
 #define BSTAMP_FLUSH                                                           \
   do {                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x == 0) {                                 \
+      st_acc[6] = bwd_stamp_now() - st_t0;                                     \
+      st_acc[7] = bwd_realtime_now() - st_r0;                                  \
+    }                                                                          \
     if ((threadIdx.x & 63) == 0)                                               \
       for (int _i = 0; _i < 8; ++_i) atomicAdd(&g_bwd_stamps[_i], st_acc[_i]); \
   } while (0)
@@ -85,7 +96,8 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
   float* dhr = lds + kRows * NC;     // [32][D] recurrent dh for the next (earlier) step
   float4* wl = reinterpret_cast<float4*>(dhr + kRows * D);  // [NW1][QL][64] W^T fragments
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile choices become SALU branches
   const int li = lane & 31, kh = lane >> 5;
   const int ta = wave % TA;          // my tile row of dW / my column tile of d[x|h]
   const int tb0 = wave / TA;         // my dW tile columns: tb0 + j*WPT
@@ -142,30 +154,55 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
   // under the MFMAs of the previous chunk's last step.
   float4 dc[NPASS];
   float4 pg[NPASS][4], pcl[NPASS], pcp[NPASS], pdh[NPASS], pdr[NPASS];
-  // Branch-free: rows past n read row n-1 and are zeroed in phase A (a zero dh makes every gate
-  // gradient of the row zero); the missing c_{-1} of step 0 reads c_0 and is zeroed there too.
+  // Branch-free: rows past n read the last valid row and are zeroed in phase A (a zero dh makes every
+  // gate gradient of the row zero); the missing c_{-1} of step 0 reads c_0 and is zeroed there too.
+  // Addresses = wave-uniform 64-bit base (SALU) + a 32-bit lane offset: address VALU is not free
+  // next to fp32 MFMAs (they share the SIMD's fp32 lanes).
   auto prefetch = [&](int64_t row0, int ts) {
+    const int last = (int)(n - 1 - row0 < kRows - 1 ? n - 1 - row0 : kRows - 1);  // uniform
+    const int64_t e0 = row0 * t + ts;
+    const float* gbase = gates + e0 * NC;
+    const float* cbase = cell + e0 * D;
+    const float* pbase = cbase - (ts > 0 ? D : 0);
+    const float* hbase = dh_ext + row0 * ld_dhe + (int64_t)ts * D;
+    const float* dbase = drop ? drop + e0 * D : nullptr;
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      const int64_t grow = row0 + p * RPP + prow;
-      const int64_t gr = grow < n ? grow : n - 1;
-      const int64_t e = gr * t + ts;
-      const float* gp = gates + e * NC + 4 * pc4;
-      pg[p][0] = *reinterpret_cast<const float4*>(gp);
-      pg[p][1] = *reinterpret_cast<const float4*>(gp + D);
-      pg[p][2] = *reinterpret_cast<const float4*>(gp + 2 * D);
-      pg[p][3] = *reinterpret_cast<const float4*>(gp + 3 * D);
-      pcl[p] = *reinterpret_cast<const float4*>(cell + e * D + 4 * pc4);
-      pcp[p] = *reinterpret_cast<const float4*>(cell + (e - (ts > 0)) * D + 4 * pc4);
-      pdh[p] = *reinterpret_cast<const float4*>(dh_ext + gr * ld_dhe + (int64_t)ts * D + 4 * pc4);
+      // chunk-local row, clamped; UNSIGNED offsets so the loads take the SGPR-base + VGPR-offset form
+      const uint32_t lr = p * RPP + prow < last ? p * RPP + prow : last;
+      const uint32_t eo = lr * (uint32_t)t, c4 = 4 * pc4;
+      pg[p][0] = *reinterpret_cast<const float4*>(gbase + (eo * NC + c4));
+      pg[p][1] = *reinterpret_cast<const float4*>(gbase + (eo * NC + D + c4));
+      pg[p][2] = *reinterpret_cast<const float4*>(gbase + (eo * NC + 2 * D + c4));
+      pg[p][3] = *reinterpret_cast<const float4*>(gbase + (eo * NC + 3 * D + c4));
+      pcl[p] = *reinterpret_cast<const float4*>(cbase + (eo * D + c4));
+      pcp[p] = *reinterpret_cast<const float4*>(pbase + (eo * D + c4));
+      pdh[p] = *reinterpret_cast<const float4*>(hbase + (lr * (uint32_t)ld_dhe + c4));
       // applied in phase A: multiplying here would wait for the loads right away
-      if (drop) pdr[p] = *reinterpret_cast<const float4*>(drop + e * D + 4 * pc4);
+      if (drop) pdr[p] = *reinterpret_cast<const float4*>(dbase + (eo * D + c4));
+    }
+  };
+  // A operand of MFMA 2 for item (row0, ts): my 32 columns of [x_t | h_{t-1}], rows 2kk + kh; loaded
+  // one item ahead like the phase-A operands (rows past n: clamped here, zeroed when consumed)
+  float a2n[16];
+  auto prefetch_a2 = [&](int64_t row0, int ts) {
+    const int last = (int)(n - 1 - row0 < kRows - 1 ? n - 1 - row0 : kRows - 1);
+    const float* src = h_side ? h + (row0 * t + (ts > 0 ? ts - 1 : 0)) * D + 32 * (ta - XT)
+                              : x + row0 * ld_n + (int64_t)ts * ld_t + 32 * ta;
+    const uint32_t ldr = h_side ? (uint32_t)(t * D) : (uint32_t)ld_n;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const uint32_t lr = 2 * kk + kh < last ? 2 * kk + kh : last;
+      a2n[kk] = src[lr * ldr + (uint32_t)li];
     }
   };
 
   int64_t ch = blockIdx.x;
   int ts = t - 1;
-  if (ch < n_chunks) prefetch(ch * kRows, ts);
+  if (ch < n_chunks) {
+    prefetch(ch * kRows, ts);
+    prefetch_a2(ch * kRows, ts);
+  }
   BSTAMP_DECL;
   while (ch < n_chunks) {
     const int64_t row0 = ch * kRows;
@@ -228,22 +265,16 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
     __syncthreads();  // dG complete; dhr consumed
     BSTAMP(1);
 
-    // ---- global operands: A of MFMA 2 (my 32 columns of [x_t | h_{t-1}], rows 2kk + kh), used after
-    // MFMA 1; then the next item's phase-A operands, in flight under both MFMA phases ---------------
+    // ---- this item's MFMA-2 operand (requested one item ago); then the next item's global operands,
+    // in flight under both MFMA phases ----------------------------------------------------------------
     const bool do_w = !h_side || ts > 0;  // h_{-1} = 0 contributes nothing
     float a2[16];
-    {
-      const float* src = h_side ? h + (int64_t)(ts > 0 ? ts - 1 : 0) * D + 32 * (ta - XT) + li_
-                                : x + (int64_t)ts * ld_t + 32 * ta + li_;
-      const int64_t ldr = h_side ? (int64_t)t * D : ld_n;
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        const int64_t grow = row0 + 2 * kk + kh_;
-        const float v = src[(grow < n ? grow : n - 1) * ldr];  // clamped: no branch around the load
-        a2[kk] = (grow < n && do_w) ? v : 0.f;
-      }
+    for (int kk = 0; kk < 16; ++kk) a2[kk] = (row0 + 2 * kk + kh_ < n) ? a2n[kk] : 0.f;
+    if (nch < n_chunks) {
+      prefetch(nch * kRows, nts);
+      prefetch_a2(nch * kRows, nts);
     }
-    if (nch < n_chunks) prefetch(nch * kRows, nts);
     BSTAMP(2);
 
     // ---- MFMA 1: one 32-column tile of d[x_t | h_{t-1}] = dG @ W^T per wave. For ts > 0 wave w
@@ -402,6 +433,8 @@ extern "C" int sagnn_lstm_bwd_f32(const float* x, int64_t ld_n, int64_t ld_t, co
     return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
   if (ld_n < d || (t > 1 && ld_t < d) || ld_dhe < (int64_t)t * d)
     return sagnn::fail(SAGNN_ERR_ARG, "strides smaller than the rows they address");
+  if (ld_n >= (1 << 25) || ld_dhe >= (1 << 25) || (int64_t)t * d >= (1 << 20))
+    return sagnn::fail(SAGNN_ERR_ARG, "lstm_bwd: row strides must stay below 2^25 floats (32-bit lane offsets)");
   if ((ld_dhe & 3) || !sagnn::aligned16(dh_ext) || !sagnn::aligned16(gates) || !sagnn::aligned16(cell) ||
       !sagnn::aligned16(W) || (drop_scale && !sagnn::aligned16(drop_scale)))
     return sagnn::fail(SAGNN_ERR_ALIGN, "lstm_bwd: need 16-byte aligned rows");
