@@ -133,13 +133,14 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Wf = lds;                                            // 2D x 4D floats
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar: tile bases stay on the SALU
   float* stage = lds + 2 * D * NC + wave * (kRowsPerWave * D);  // private [32][D]
   const int ai = lane & 31, kh = lane >> 5;                   // A layout: row, k parity
   const int cj = lane & 31, rh = lane >> 5;                   // C layout: column, row half
 
   load_weight_fragments<NC>(Wf, W, 2 * D);
   __syncthreads();
+  STAMP_DECL;
 
   float bcol[CT];
 #pragma unroll
@@ -156,6 +157,18 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[ht][r] = 0.f;
 
+    // Global traffic of the tile goes through buffer descriptors: a wave-uniform base (SALU), 32-bit
+    // lane offsets, and rows past n dropped by the hardware range check — the 64-bit per-element
+    // address arithmetic and row predicates this replaces were a third of the gate phase (VALU work
+    // is not hidden by the fp32 MFMAs).
+    const int rows_valid = (int)(n - row0 < kRowsPerWave ? n - row0 : kRowsPerWave);
+    const auto rs_h = __builtin_amdgcn_make_buffer_rsrc(h_out + row0 * ld_h, 0, rows_valid * (int)ld_h * 4, 0x00020000);
+    const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(SAVE ? gates_out + row0 * t * NC : h_out, 0,
+                                                        SAVE ? rows_valid * t * NC * 4 : 0, 0x00020000);
+    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(SAVE ? c_out + row0 * t * D : h_out, 0,
+                                                        SAVE ? rows_valid * t * D * 4 : 0, 0x00020000);
+    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(drop ? drop + row0 * t * D : x), 0,
+                                                        drop ? rows_valid * t * D * 4 : 0, 0x00020000);
     float4 xr[NFILL];
     auto fetch_x = [&](int ts) {
 #pragma unroll
@@ -167,6 +180,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
     };
     fetch_x(0);
 
+    STAMP(5);
     for (int ts = 0; ts < t; ++ts) {
       // Lane-derived LDS offsets are recomputed every step (a handful of VALU ops against 256+
       // MFMAs): left loop-invariant, the compiler hoists ~100 swizzled addresses out of the
@@ -192,6 +206,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) a_x[kk] = stage[ai_ * D + ((2 * kk + kh_) ^ ai_)];
       if (ts + 1 < t) fetch_x(ts + 1);  // in flight under the MFMAs below
+      STAMP(0);
 
       // ---- gates = x_t @ W[0:D] + h @ W[D:2D]  (bias joins in the gate math) -------------
       f32x16 acc[CT];
@@ -200,8 +215,10 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
       mfma_half<KS, HF>(acc, a_x, Wf, 0, lane);
+      STAMP(1);
       if (ts > 0)  // h_0 = 0: the recurrent half contributes nothing at the first step
         mfma_half<KS, HF>(acc, a_h, Wf, KS, lane);
+      STAMP(2);
 
       // ---- gate math in the C layout (columns i | j | f | o, each D wide) ----------------
       __builtin_amdgcn_wave_barrier();
@@ -219,24 +236,24 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
           const int row = crow(r, rh_);
           const int col = ht * 32 + cj_;
           stage[row * D + (col ^ row)] = hn;  // for the next step's A operand
-          const int64_t grow = row0 + row;
-          if (SAVE && grow < n) {
-            float* gp = gates_out + (grow * t + ts) * (int64_t)(4 * D) + col;
-            gp[0] = si;
-            gp[D] = tj;
-            gp[2 * D] = sf;
-            gp[3 * D] = so;
-            c_out[(grow * t + ts) * (int64_t)D + col] = cn;
+          // element (row, ts, col) of an [n, t, D] tensor, in floats from the tile's first row
+          const int e_td = (row * t + ts) * D + col;
+          if (SAVE) {
+            const int go = (row * t + ts) * NC + col;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, si), rs_g, go * 4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, tj), rs_g, (go + D) * 4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sf), rs_g, (go + 2 * D) * 4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, so), rs_g, (go + 3 * D) * 4, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, cn), rs_c, e_td * 4, 0, 0);
           }
-          if (grow < n) {
-            float hv = hn;
-            if (drop) hv *= drop[grow * (int64_t)t * D + (int64_t)ts * D + col];
-            h_out[grow * ld_h + (int64_t)ts * D + col] = hv;
-          }
+          float hv = hn;
+          if (drop) hv *= __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_d, e_td * 4, 0, 0));
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hv), rs_h, (row * (int)ld_h + ts * D + col) * 4, 0, 0);
           // keep the scheduler from interleaving all 16*HT chains (register pressure)
           if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
       }
+      STAMP(3);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -245,8 +262,10 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
         for (int kk = 0; kk < KS; ++kk) a_h[kk] = stage[ai_ * D + ((2 * kk + kh_) ^ ai_)];
       }
       __builtin_amdgcn_wave_barrier();
+      STAMP(4);
     }
   }
+  STAMP_FLUSH;
 }
 
 
@@ -751,6 +770,9 @@ int lstm_fwd_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, 
                   const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
                   float* gates_out, float* c_out, hipStream_t s) {
   const bool save = gates_out != nullptr;
+  // 32-row tiles are addressed with 32-bit byte offsets from a per-tile base
+  if (ld_n >= (1 << 24) || ld_h >= (1 << 24) || (int64_t)t * d >= (1 << 20))
+    return fail(SAGNN_ERR_ARG, "MFMA LSTM: row strides must stay below 2^24 floats");
   if (d == 64 && save) return launch_lstm_mfma<64, true>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, s);
   if (d == 64) return launch_lstm_mfma<64, false>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, nullptr, nullptr, s);
   if (d == 32 && save) return launch_lstm_mfma<32, true>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, s);
