@@ -305,11 +305,14 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
         c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, c1, 0, 0, 0);
       }
       if (m1 < XT) {
+        // per-chunk buffer descriptor: uniform base, 32-bit lane offsets, rows past n dropped by the
+        // hardware range check (no 64-bit address arithmetic or predicates per element)
+        const int rows_valid = (int)(n - row0 < kRows ? n - row0 : kRows);
+        const auto rs_dx = __builtin_amdgcn_make_buffer_rsrc(dx + row0 * t * D, 0, rows_valid * t * D * 4, 0x00020000);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int64_t grow = row0 + crow(r, kh_);
-          if (grow < n) dx[(grow * t + ts) * D + 32 * m1 + li_] = c0[r] + c1[r];
-        }
+        for (int r = 0; r < 16; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c0[r] + c1[r]), rs_dx,
+                                                ((crow(r, kh_) * t + ts) * D + 32 * m1 + li_) * 4, 0, 0);
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dhr[crow(r, kh_) * D + 32 * (m1 - XT) + li_] = c0[r] + c1[r];
