@@ -301,6 +301,16 @@ int sagnn_layernorm_td_bwd_f32(const float* h, int64_t ld_h, const float* dy, in
 int sagnn_lstm_bwd_step_f32(const float* gates, const float* cell, const float* dh_ext, int64_t ld_dhe,
                             const float* drop_scale, const float* dh_rec, int64_t ld_dhr, const float* dc_in,
                             float* dgates, float* dc_out, int64_t n, int t, int d, int ts, void* stream);
+/* Front of the attention backward pass in one launch (sagnn_attn_bwd_front_supported: d in {32, 64},
+ * d_k in {2, 4}, t in {1..6, 8}): y = layer_norm(x) when apply_ln (else x), Q|K|V = y W + b, attention
+ * backward given g_out = dL/d(mean context) [n, d] -> dqkv [n*t, 3d] (dQ | dK | dV rows) and, when
+ * y_out is not NULL, y [n*t, d]. Replaces layernorm_td + dense_nn + attn_bwd of the recompute path. */
+int sagnn_attn_bwd_front_supported(int d, int t, int heads);
+int sagnn_attn_bwd_front_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
+                             const float* ln_gamma, const float* ln_beta, float ln_eps, int apply_ln,
+                             const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv,
+                             const float* bv, const float* g_out, int64_t ld_g, float* dqkv, float* y_out,
+                             void* stream);
 int sagnn_lstm_bwd_supported(int d);
 int sagnn_lstm_bwd_f32(const float* x, int64_t ld_n, int64_t ld_t, const float* h, const float* gates,
                        const float* cell, const float* dh_ext, int64_t ld_dhe, const float* drop_scale,

@@ -57,6 +57,23 @@ def _split_qkv_grads(dWqkv, dbqkv, d):
     return out
 
 
+def _attn_bwd_front(x, gamma, beta, Wq, bq, Wk, bk, Wv, bv, heads, g_out, want_y=True):
+    """sagnn_attn_bwd_front_f32: x [n, t, d] dense, g_out [n, d] -> (y [n*t, d] or None, dqkv [n*t, 3d]).
+    gamma None = no layer norm (y = x, not written)."""
+    lib = ops._lib.load()
+    n, t, d, ld_n, ld_t = ops._ntd("x", x)
+    dev = x.device
+    dqkv = torch.empty((n * t, 3 * d), dtype=torch.float32, device=dev)
+    y = torch.empty((n * t, d), dtype=torch.float32, device=dev) if (want_y and gamma is not None) else None
+    vec = lambda name, v, cnt: ops._vec(name, v.detach(), cnt)   # noqa: E731
+    ops.check(lib.sagnn_attn_bwd_front_f32(
+        x.data_ptr(), ld_n, ld_t, n, t, d, int(heads), None if gamma is None else vec("gamma", gamma, d),
+        None if beta is None else vec("beta", beta, d), 1e-12, 0 if gamma is None else 1, vec("Wq", Wq, d * d),
+        vec("bq", bq, d), vec("Wk", Wk, d * d), vec("bk", bk, d), vec("Wv", Wv, d * d), vec("bv", bv, d),
+        g_out.data_ptr(), int(g_out.stride(0)), dqkv.data_ptr(), ops._ptr(y), ops._stream()))
+    return y, dqkv
+
+
 def lstm_bwd(x, h, gates, cell, dh, drop, W):
     """Whole BPTT in one launch (sagnn_lstm_bwd_f32, d in {32, 64}): x [n, t, d] (any strides),
     h / gates / cell as the training forward stored them, dh [n, t, d] dense = gradient at the
@@ -117,15 +134,17 @@ class IntervalFusionFn(torch.autograd.Function):
         dev = x.device
         st = ops._stream()
         g_out = g_out.contiguous()
-        # ---- recompute y and Q|K|V ---------------------------------------------------------
+        # ---- recompute y and Q|K|V, attention backward -> dQ|dK|dV -----------------------------
         h_emit = h if drop is None else ops.mul(h, drop.contiguous())
-        y = ops.layernorm_td(h_emit, ln_gamma.detach(), ln_beta.detach())                # [n, t, d]
         Wqkv = torch.cat([Wq, Wk, Wv], dim=1).detach().contiguous()                      # [d, 3d]
-        bqkv = torch.cat([bq, bk, bv]).detach().contiguous()
-        y2 = y.view(n * t, d)
-        qkv = ops.dense_nn(y2, Wqkv, bqkv)                                               # [n*t, 3d]
-        # ---- attention backward, in place: qkv -> dQ|dK|dV -----------------------------------
-        ops.check(lib.sagnn_attn_bwd_f32(qkv.data_ptr(), g_out.data_ptr(), d, n, t, d, heads, st))
+        if lib.sagnn_attn_bwd_front_supported(d, t, heads) and os.environ.get("SAGNN_ATTN_BWD", "") != "steps":
+            y2, qkv = _attn_bwd_front(h_emit, ln_gamma.detach(), ln_beta.detach(), Wq, bq, Wk, bk, Wv, bv, heads, g_out)
+        else:
+            y = ops.layernorm_td(h_emit, ln_gamma.detach(), ln_beta.detach())            # [n, t, d]
+            bqkv = torch.cat([bq, bk, bv]).detach().contiguous()
+            y2 = y.view(n * t, d)
+            qkv = ops.dense_nn(y2, Wqkv, bqkv)                                           # [n*t, 3d]
+            ops.check(lib.sagnn_attn_bwd_f32(qkv.data_ptr(), g_out.data_ptr(), d, n, t, d, heads, st))
         dWqkv = torch.zeros((d, 3 * d), dtype=torch.float32, device=dev)
         dbqkv = torch.zeros(3 * d, dtype=torch.float32, device=dev)
         ops.dense_tn(y2, qkv, dWqkv, dbqkv)
@@ -185,8 +204,11 @@ def _mhsa_mean_backward(y, Wq, bq, Wk, bk, Wv, bv, heads, g_out):
     Wqkv = torch.cat([Wq, Wk, Wv], dim=1).detach().contiguous()
     bqkv = torch.cat([bq, bk, bv]).detach().contiguous()
     y2 = y.reshape(n * t, d)
-    qkv = ops.dense_nn(y2, Wqkv, bqkv)
-    ops.check(lib.sagnn_attn_bwd_f32(qkv.data_ptr(), g_out.data_ptr(), d, n, t, d, heads, ops._stream()))
+    if lib.sagnn_attn_bwd_front_supported(d, t, heads) and os.environ.get("SAGNN_ATTN_BWD", "") != "steps":
+        _, qkv = _attn_bwd_front(y.contiguous(), None, None, Wq, bq, Wk, bk, Wv, bv, heads, g_out.contiguous())
+    else:
+        qkv = ops.dense_nn(y2, Wqkv, bqkv)
+        ops.check(lib.sagnn_attn_bwd_f32(qkv.data_ptr(), g_out.data_ptr(), d, n, t, d, heads, ops._stream()))
     dWqkv = torch.zeros((d, 3 * d), dtype=torch.float32, device=dev)
     dbqkv = torch.zeros(3 * d, dtype=torch.float32, device=dev)
     ops.dense_tn(y2, qkv, dWqkv, dbqkv)

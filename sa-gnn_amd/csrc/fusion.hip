@@ -485,6 +485,33 @@ extern "C" int sagnn_ln_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t ld_t
   return sagnn_mhsa_mean_f32(y, ldw, d, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out, stream);
 }
 
+// Front of the attention backward pass in one launch (d in {32, 64}, d_k in {2, 4}, t in {1..6, 8}):
+// y = LN(x) (apply_ln) or x, Q|K|V = y W + b on the matrix cores, attention backward per (node, head)
+// in registers -> dqkv [n*t, 3d]; y [n*t, d] is written when y_out is given (operand of dW = y^T dQKV).
+extern "C" int sagnn_attn_bwd_front_supported(int d, int t, int heads) {
+  return sagnn::attn_bwd_front_supported(d, t, heads) && !sagnn::force_valu();
+}
+
+extern "C" int sagnn_attn_bwd_front_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
+                                        const float* ln_gamma, const float* ln_beta, float ln_eps, int apply_ln,
+                                        const float* Wq, const float* bq, const float* Wk, const float* bk,
+                                        const float* Wv, const float* bv, const float* g_out, int64_t ld_g,
+                                        float* dqkv, float* y_out, void* stream) {
+  if (int rc = check_dims(n, t, d)) return rc;
+  if (!sagnn::attn_bwd_front_supported(d, t, heads))
+    return sagnn::fail(SAGNN_ERR_DIM, "attn_bwd_front: unsupported d = %d, t = %d, heads = %d", d, t, heads);
+  if (!x || !Wq || !bq || !Wk || !bk || !Wv || !bv || !g_out || !dqkv || (apply_ln && (!ln_gamma || !ln_beta)))
+    return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (int rc = check_strides(ld_n, ld_t, n, t, d)) return rc;
+  if (ld_g < d) return sagnn::fail(SAGNN_ERR_ARG, "ld_g smaller than d");
+  if (!sagnn::aligned16(x) || (ld_n & 3) || (ld_t & 3) || !sagnn::aligned16(g_out) || (ld_g & 3) ||
+      !sagnn::aligned16(dqkv) || (y_out && !sagnn::aligned16(y_out)))
+    return sagnn::fail(SAGNN_ERR_ALIGN, "attn_bwd_front: need 16-byte aligned rows");
+  if (n == 0) return SAGNN_OK;
+  return sagnn::attn_bwd_front_mfma(x, ld_n, ld_t, n, t, d, heads, ln_gamma, ln_beta, ln_eps, apply_ln, Wq, bq, Wk, bk,
+                                    Wv, bv, g_out, ld_g, dqkv, y_out, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int sagnn_lstm_fwd_train_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
                                         const float* W, const float* b, float forget_bias,
                                         const float* drop_scale, float* h, int64_t ld_h, float* gates,

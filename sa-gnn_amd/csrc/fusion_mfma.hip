@@ -456,6 +456,75 @@ __device__ __forceinline__ void attention_pairs(const float* __restrict__ qkv, i
   }
 }
 
+// Backward of the pair form, in place on the wave's Q|K|V tile: each lane turns the Q, K, V rows of
+// its (node, head) pair into dQ, dK, dV given g = dL/d(mean context) / T (Utils/attention.py:35-45
+// differentiated; same formulas as attn_bwd_kernel in fusion_bwd.hip):
+//   a_qs = e_qs / (R_q + 1e-8), p_s = g . V[s], dz_qs = a_qs (p_s - sum_s' a_qs' p_s'),
+//   dQ[q] = scale sum_s dz_qs K[s], dK[s] = scale sum_q dz_qs Q[q], dV[s] = g sum_q a_qs.
+template <int D, int DK, int QS, int T>
+__device__ __forceinline__ void attention_pairs_bwd(float* __restrict__ qkv, int nb_per_wave, int lane, float scale,
+                                                    float inv_t, int64_t node0, int64_t n,
+                                                    const float* __restrict__ g_out, int64_t ld_g) {
+  constexpr int H = D / DK;
+  typedef float vec __attribute__((ext_vector_type(DK)));
+  const int pairs = nb_per_wave * H;
+  for (int p = lane; p < pairs; p += kWave) {
+    const int nb = p / H, hd = p - nb * H;
+    float* base = qkv + nb * T * QS + hd * DK;
+    vec q[T], k[T], v[T], dk[T];
+    float ps[T], asum[T];
+    const int64_t node = node0 + nb;
+    vec g = (vec)(0.f);
+    if (node < n) g = *reinterpret_cast<const vec*>(g_out + node * ld_g + hd * DK) * inv_t;
+#pragma unroll
+    for (int ts = 0; ts < T; ++ts) {
+      q[ts] = *reinterpret_cast<const vec*>(base + ts * QS);
+      k[ts] = *reinterpret_cast<const vec*>(base + ts * QS + D);
+      v[ts] = *reinterpret_cast<const vec*>(base + ts * QS + 2 * D);
+      dk[ts] = (vec)(0.f);
+      asum[ts] = 0.f;
+      float pd = g[0] * v[ts][0];
+#pragma unroll
+      for (int c = 1; c < DK; ++c) pd = fmaf(g[c], v[ts][c], pd);
+      ps[ts] = pd;
+    }
+#pragma unroll
+    for (int tq = 0; tq < T; ++tq) {
+      float a[T];
+      float rs = 0.f;
+#pragma unroll
+      for (int s = 0; s < T; ++s) {
+        float z = q[tq][0] * k[s][0];
+#pragma unroll
+        for (int c = 1; c < DK; ++c) z = fmaf(q[tq][c], k[s][c], z);
+        a[s] = __expf(z * scale);
+        rs += a[s];
+      }
+      const float inv = __builtin_amdgcn_rcpf(rs + 1e-8f);
+      float dot = 0.f;
+#pragma unroll
+      for (int s = 0; s < T; ++s) {
+        a[s] *= inv;
+        dot = fmaf(a[s], ps[s], dot);
+      }
+      vec dq = (vec)(0.f);
+#pragma unroll
+      for (int s = 0; s < T; ++s) {
+        const float dz = a[s] * (ps[s] - dot);
+        dq += dz * k[s];
+        dk[s] += dz * q[tq];
+        asum[s] += a[s];
+      }
+      *reinterpret_cast<vec*>(base + tq * QS) = dq * scale;
+    }
+#pragma unroll
+    for (int ts = 0; ts < T; ++ts) {
+      *reinterpret_cast<vec*>(base + ts * QS + D) = dk[ts] * scale;
+      *reinterpret_cast<vec*>(base + ts * QS + 2 * D) = g * asum[ts];
+    }
+  }
+}
+
 // Head-split form with a compile-time T (a multiple of DK): as attention_heads, but the key and
 // value vectors of a lane's positions are read once per node instead of once per query, and every
 // loop has a constant trip count.
@@ -522,13 +591,19 @@ __device__ __forceinline__ void load_square_fragments(float* __restrict__ Wf,
 
 // TT: number of intervals known at compile time (0 = run-time t): picks the attention form and lets
 // the row loops of the normalisation unroll.
-template <int D, int TT>
+// BWD (needs 1 <= TT <= 8): the front of the backward pass instead of the forward tail — the same
+// normalisation and Q|K|V tile, then the pair-form attention backward in place on the tile; writes
+// dQ|dK|dV [n*t, 3D] (dqkv_out) and the normalised rows y [n*t, D] (y_out, operand of dW = y^T dQKV)
+// given g_out = dL/d(out) [n, D] (row stride ld_out); `out` is not written.
+template <int D, int TT, bool BWD>
 __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
     const float* __restrict__ x, int64_t ld_n, int64_t ld_t, int64_t n, int t_rt, int heads,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, int apply_ln,
     const float* __restrict__ Wq, const float* __restrict__ bq, const float* __restrict__ Wk,
     const float* __restrict__ bk, const float* __restrict__ Wv, const float* __restrict__ bv,
-    float* __restrict__ out, int64_t ld_out, int64_t n_tiles) {
+    float* __restrict__ out, int64_t ld_out, int64_t n_tiles, const float* __restrict__ g_out,
+    float* __restrict__ dqkv_out, float* __restrict__ y_out) {
+  static_assert(!BWD || (TT >= 1 && TT <= 8), "backward front needs the pair form");
   constexpr int TM = D / 32;       // 32-column tiles per weight matrix
   constexpr int KS = D / 2;        // k-steps
   constexpr int LPR = D / 4;
@@ -650,6 +725,31 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
     }
 
     STAMP(1);
+    if (BWD && y_out) {
+      // normalised rows back through the (now free) fill tile, then out as whole rows: tile row m is
+      // global row node0*t + m
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) stage[ai_ * D + ((2 * kk + kh_) ^ ai_)] = a[kk];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int64_t left = (n - node0) * t;
+      const int rows_ok = (int)(left < rows_used ? left : rows_used);
+      const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(y_out + node0 * t * D, 0, rows_ok * D * 4, 0x00020000);
+#pragma unroll
+      for (int q = 0; q < NFILL; ++q) {
+        const int m = q * RPI + fr_;
+        const float* src = stage + m * D;
+        const int sw = m & 31;
+        const float y0 = src[(fc4_ + 0) ^ sw], y1 = src[(fc4_ + 1) ^ sw], y2 = src[(fc4_ + 2) ^ sw], y3 = src[(fc4_ + 3) ^ sw];
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4 pk = {__builtin_bit_cast(int, y0), __builtin_bit_cast(int, y1), __builtin_bit_cast(int, y2),
+                          __builtin_bit_cast(int, y3)};
+        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_y, (m * D + fc4_) * 4, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();  // tile reads done before the Q|K|V tile overwrites it
+    }
     // ---- Q | K | V = A @ W + b ---------------------------------------------------------------
     f32x16 aq[TM], ak[TM], av[TM];
 #pragma unroll
@@ -713,7 +813,27 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
     // ---- attention per node and head ---------------------------------------------------------
     // NPAR nodes are interleaved for ILP; with few nodes per wave (large t) extra slots are waste
     const bool wide = nb_per_wave >= 4 * (kWave / D);
-    if (TT >= 1 && TT <= 8 && (dk == 4 || dk == 2)) {
+    if (BWD) {
+      constexpr int TB = (TT >= 1 && TT <= 8) ? TT : 1;
+      if (dk == 4) attention_pairs_bwd<D, 4, QS, TB>(qkv, nb_per_wave, lane, scale, inv_t, node0, n, g_out, ld_out);
+      else attention_pairs_bwd<D, 2, QS, TB>(qkv, nb_per_wave, lane, scale, inv_t, node0, n, g_out, ld_out);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      // dQ|dK|dV tile out as whole rows (3D floats each)
+      const int64_t left = (n - node0) * t;
+      const int rows_ok = (int)(left < rows_used ? left : rows_used);
+      const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(dqkv_out + node0 * t * 3 * D, 0, rows_ok * 3 * D * 4, 0x00020000);
+      constexpr int V4 = 3 * D / 4;  // float4 per row
+      for (int i = lane; i < rows_used * V4; i += kWave) {
+        const int m = i / V4, c4 = (i - m * V4) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(qkv + m * QS + c4);
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4 pk = {__builtin_bit_cast(int, v.x), __builtin_bit_cast(int, v.y), __builtin_bit_cast(int, v.z),
+                          __builtin_bit_cast(int, v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(pk, rs_q, (m * 3 * D + c4) * 4, 0, 0);
+      }
+    } else if (TT >= 1 && TT <= 8 && (dk == 4 || dk == 2)) {
       if (dk == 4) attention_pairs<D, 4, QS, (TT >= 1 && TT <= 8) ? TT : 1>(qkv, nb_per_wave, lane, scale, inv_t, node0, n, out, ld_out);
       else attention_pairs<D, 2, QS, (TT >= 1 && TT <= 8) ? TT : 1>(qkv, nb_per_wave, lane, scale, inv_t, node0, n, out, ld_out);
     } else if (TT > 8 && dk == 4 && TT % 4 == 0) {
@@ -786,15 +906,16 @@ bool mhsa_mfma_supported(int d, int t, int heads) {
   return (dk & (dk - 1)) == 0;  // the per-head lane reduction needs a power of two
 }
 
-template <int D, int TT>
+template <int D, int TT, bool BWD>
 static int launch_ln_mhsa_t(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int heads,
                             const float* gamma, const float* beta, float eps, int apply_ln,
                             const float* Wq, const float* bq, const float* Wk, const float* bk,
-                            const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s) {
+                            const float* Wv, const float* bv, float* out, int64_t ld_out, const float* g_out,
+                            float* dqkv_out, float* y_out, hipStream_t s) {
   const size_t lds = (size_t)(3 * D * D + 4 * kRowsPerWave * (3 * D + 4)) * sizeof(float);
   static bool configured = false;
   if (!configured) {
-    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_mhsa_mean_mfma_kernel<D, TT>),
+    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_mhsa_mean_mfma_kernel<D, TT, BWD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     configured = true;
   }
@@ -807,9 +928,9 @@ static int launch_ln_mhsa_t(const float* x, int64_t ld_n, int64_t ld_t, int64_t 
   const int64_t n_tiles = (n + nodes_per_tile - 1) / nodes_per_tile;
   const int64_t blocks = n_tiles < cus ? n_tiles : cus;
   ProfileScope prof(kProfMhsa, s, n, t);
-  hipLaunchKernelGGL((ln_mhsa_mean_mfma_kernel<D, TT>), dim3((unsigned)blocks), dim3(kBlock), lds, s, x, ld_n,
+  hipLaunchKernelGGL((ln_mhsa_mean_mfma_kernel<D, TT, BWD>), dim3((unsigned)blocks), dim3(kBlock), lds, s, x, ld_n,
                      ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out,
-                     n_tiles);
+                     n_tiles, g_out, dqkv_out, y_out);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
@@ -822,11 +943,11 @@ static int launch_ln_mhsa(const float* x, int64_t ld_n, int64_t ld_t, int64_t n,
                           const float* Wq, const float* bq, const float* Wk, const float* bk,
                           const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s) {
 #define SAGNN_T_CASE(TT) \
-  case TT: return launch_ln_mhsa_t<D, TT>(x, ld_n, ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
+  case TT: return launch_ln_mhsa_t<D, TT, false>(x, ld_n, ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, nullptr, nullptr, nullptr, s);
   switch (t) {
     SAGNN_T_CASE(1) SAGNN_T_CASE(2) SAGNN_T_CASE(3) SAGNN_T_CASE(4) SAGNN_T_CASE(5) SAGNN_T_CASE(6)
     SAGNN_T_CASE(8) SAGNN_T_CASE(12) SAGNN_T_CASE(16)
-    default: return launch_ln_mhsa_t<D, 0>(x, ld_n, ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
+    default: return launch_ln_mhsa_t<D, 0, false>(x, ld_n, ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, nullptr, nullptr, nullptr, s);
   }
 #undef SAGNN_T_CASE
 }
@@ -841,6 +962,38 @@ int ln_mhsa_mean_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int
   if (d == 32)
     return launch_ln_mhsa<32>(x, ld_n, ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
   return fail(SAGNN_ERR_DIM, "MFMA attention supports d = 32 or 64, got %d", d);
+}
+
+bool attn_bwd_front_supported(int d, int t, int heads) {
+  if (!mhsa_mfma_supported(d, t, heads)) return false;
+  const int dk = d / heads;
+  return (dk == 2 || dk == 4) && ((t >= 1 && t <= 6) || t == 8);
+}
+
+template <int D>
+static int launch_attn_bwd_front(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int heads,
+                                 const float* gamma, const float* beta, float eps, int apply_ln, const float* Wq,
+                                 const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
+                                 const float* g_out, int64_t ld_g, float* dqkv, float* y, hipStream_t s) {
+#define SAGNN_T_CASE(TT) \
+  case TT: return launch_ln_mhsa_t<D, TT, true>(x, ld_n, ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, nullptr, ld_g, g_out, dqkv, y, s);
+  switch (t) {
+    SAGNN_T_CASE(1) SAGNN_T_CASE(2) SAGNN_T_CASE(3) SAGNN_T_CASE(4) SAGNN_T_CASE(5) SAGNN_T_CASE(6) SAGNN_T_CASE(8)
+    default: return fail(SAGNN_ERR_DIM, "attention backward front: t = %d has no specialised kernel", t);
+  }
+#undef SAGNN_T_CASE
+}
+
+// Front of the attention backward pass: y = LN(x) (or x), Q|K|V, attention backward -> dqkv [n*t, 3d], y [n*t, d].
+int attn_bwd_front_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
+                        const float* gamma, const float* beta, float eps, int apply_ln, const float* Wq,
+                        const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
+                        const float* g_out, int64_t ld_g, float* dqkv, float* y, hipStream_t s) {
+  if (d == 64)
+    return launch_attn_bwd_front<64>(x, ld_n, ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, g_out, ld_g, dqkv, y, s);
+  if (d == 32)
+    return launch_attn_bwd_front<32>(x, ld_n, ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, g_out, ld_g, dqkv, y, s);
+  return fail(SAGNN_ERR_DIM, "attention backward front supports d = 32 or 64, got %d", d);
 }
 
 }  // namespace sagnn

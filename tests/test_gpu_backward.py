@@ -72,7 +72,8 @@ def test_autograd_function_end_to_end(dev):
     np.testing.assert_allclose(pi.grad.cpu().numpy(), ti.grad.numpy(), rtol=2e-4, atol=1e-5 * s)
 
 
-@pytest.mark.parametrize("d,t,n,heads", [(64, 3, 300, 16), (32, 2, 130, 16), (64, 1, 70, 16), (64, 5, 97, 4), (128, 3, 90, 16)])
+@pytest.mark.parametrize("d,t,n,heads", [(64, 3, 300, 16), (32, 2, 130, 16), (64, 1, 70, 16), (64, 5, 97, 4), (128, 3, 90, 16),
+                                          (64, 8, 41, 16), (32, 6, 53, 16), (64, 12, 19, 16)])
 def test_interval_fusion_backward_vs_autograd(dev, d, t, n, heads):
     """Every gradient of the fusion (x and all ten parameter tensors) against float64 autograd."""
     from sa_gnn_amd import autograd as ag
