@@ -168,6 +168,118 @@ __global__ void layernorm_td_bwd_kernel(const float* __restrict__ h, int64_t ld_
   }
 }
 
+// Vector form of the above for d a power of two: a node is held in registers by a group of LPN
+// lanes (VPL float4 each: t*d <= 4*LPN*VPL), 64/LPN nodes per wavefront at a time; h and dy are
+// read once, every lane owns 4 fixed columns (4*LPN is a multiple of d), group sums run as xor
+// shuffles inside the group, and dgamma / dbeta are reduced over the block in LDS before one
+// atomic per column and block.
+template <int VPL>
+__global__ __launch_bounds__(kBlock) void layernorm_td_bwd_vec_kernel(
+    const float* __restrict__ h, int64_t ld_h, const float* dy, int64_t ld_dy, int64_t n, int t, int d,
+    const float* __restrict__ gamma, float eps, float* dh, int64_t ld_dh, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int lpn) {
+  __shared__ float red[2 * 256];  // dgamma | dbeta partials by column (d <= 256)
+  const int lane = threadIdx.x & 63;
+  const int gl = lane & (lpn - 1);          // lane within the node's group
+  const int grp = lane / lpn;               // node slot within the wave
+  const int npw = 64 / lpn;                 // nodes per wave iteration
+  const int td = t * d;
+  const float inv_m = 1.f / (float)td;
+  const int col = (4 * gl) % d;             // my 4 columns, the same for every j (d | 4*lpn)
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + col);
+  float4 gacc = make_float4(0.f, 0.f, 0.f, 0.f), bacc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = threadIdx.x; i < 2 * 256; i += blockDim.x) red[i] = 0.f;
+  __syncthreads();
+  const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t base = wave0 * npw; base < n; base += waves * npw) {
+    const int64_t node = base + grp;
+    const bool live = node < n;
+    const int64_t nd = live ? node : n - 1;
+    float4 hv[VPL], gv[VPL];
+    bool on[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      const int i = 4 * (gl + lpn * j);
+      on[j] = i < td;
+      hv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      gv[j] = hv[j];
+      if (on[j]) {
+        hv[j] = *reinterpret_cast<const float4*>(h + nd * ld_h + i);
+        gv[j] = *reinterpret_cast<const float4*>(dy + nd * ld_dy + i);
+      }
+      s += (hv[j].x + hv[j].y) + (hv[j].z + hv[j].w);
+    }
+    for (int off = lpn >> 1; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s * inv_m;
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      if (on[j]) {
+        const float a = hv[j].x - mean, b = hv[j].y - mean, c = hv[j].z - mean, e = hv[j].w - mean;
+        v += (a * a + b * b) + (c * c + e * e);
+      }
+    }
+    for (int off = lpn >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const float rstd = rsqrtf(v * inv_m + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+      // hv becomes hhat, gv stays dy (zero where the slot is off)
+      hv[j].x = on[j] ? (hv[j].x - mean) * rstd : 0.f;
+      hv[j].y = on[j] ? (hv[j].y - mean) * rstd : 0.f;
+      hv[j].z = on[j] ? (hv[j].z - mean) * rstd : 0.f;
+      hv[j].w = on[j] ? (hv[j].w - mean) * rstd : 0.f;
+      const float dx_ = gv[j].x * gm.x, dy_ = gv[j].y * gm.y, dz_ = gv[j].z * gm.z, dw_ = gv[j].w * gm.w;
+      s1 += (dx_ + dy_) + (dz_ + dw_);
+      s2 += (dx_ * hv[j].x + dy_ * hv[j].y) + (dz_ * hv[j].z + dw_ * hv[j].w);
+      if (live) {
+        gacc.x = fmaf(gv[j].x, hv[j].x, gacc.x);
+        gacc.y = fmaf(gv[j].y, hv[j].y, gacc.y);
+        gacc.z = fmaf(gv[j].z, hv[j].z, gacc.z);
+        gacc.w = fmaf(gv[j].w, hv[j].w, gacc.w);
+        bacc.x += gv[j].x;
+        bacc.y += gv[j].y;
+        bacc.z += gv[j].z;
+        bacc.w += gv[j].w;
+      }
+    }
+    for (int off = lpn >> 1; off > 0; off >>= 1) {
+      s1 += __shfl_xor(s1, off);
+      s2 += __shfl_xor(s2, off);
+    }
+    s1 *= inv_m;
+    s2 *= inv_m;
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < VPL; ++j) {
+        if (on[j]) {
+          float4 o;
+          o.x = rstd * (gv[j].x * gm.x - s1 - hv[j].x * s2);
+          o.y = rstd * (gv[j].y * gm.y - s1 - hv[j].y * s2);
+          o.z = rstd * (gv[j].z * gm.z - s1 - hv[j].z * s2);
+          o.w = rstd * (gv[j].w * gm.w - s1 - hv[j].w * s2);
+          *reinterpret_cast<float4*>(dh + node * ld_dh + 4 * (gl + lpn * j)) = o;
+        }
+      }
+    }
+  }
+  atomicAdd(red + col + 0, gacc.x);
+  atomicAdd(red + col + 1, gacc.y);
+  atomicAdd(red + col + 2, gacc.z);
+  atomicAdd(red + col + 3, gacc.w);
+  atomicAdd(red + 256 + col + 0, bacc.x);
+  atomicAdd(red + 256 + col + 1, bacc.y);
+  atomicAdd(red + 256 + col + 2, bacc.z);
+  atomicAdd(red + 256 + col + 3, bacc.w);
+  __syncthreads();
+  for (int k = threadIdx.x; k < d; k += blockDim.x) {
+    atomicAdd(dgamma + k, red[k]);
+    atomicAdd(dbeta + k, red[256 + k]);
+  }
+}
+
 // One BPTT step on saved activations. gates [n, t, 4d] = sigmoid(i) | tanh(j) | sigmoid(f + fb) |
 // sigmoid(o); cell [n, t, d]. h = tanh(c) * o, c = c_prev * f + i * j.
 __global__ void lstm_bwd_step_kernel(const float* __restrict__ gates, const float* __restrict__ cell,
@@ -395,6 +507,30 @@ extern "C" int sagnn_layernorm_td_bwd_f32(const float* h, int64_t ld_h, const fl
   if (ld_h < (int64_t)t * d || ld_dy < (int64_t)t * d || ld_dh < (int64_t)t * d)
     return sagnn::fail(SAGNN_ERR_ARG, "node stride smaller than t*d");
   if (n == 0) return SAGNN_OK;
+  // vector form: d a power of two, 16-byte aligned rows, at most 8 float4 per lane
+  const int td4 = t * d / 4;
+  int lpn = 1;
+  while (lpn < td4 && lpn < 64) lpn <<= 1;
+  if (lpn < d / 4) lpn = d / 4;
+  const int vpl = (td4 + lpn - 1) / lpn;
+  const bool vec_ok = (d & (d - 1)) == 0 && lpn <= 64 && vpl <= 8 && sagnn::aligned16(h) && sagnn::aligned16(dy) &&
+                      sagnn::aligned16(dh) && sagnn::aligned16(gamma) && !((ld_h | ld_dy | ld_dh) & 3);
+  if (vec_ok) {
+    const int npw = 64 / lpn;
+    int64_t vblocks = (n + 4 * npw - 1) / (4 * npw);
+    if (vblocks > 4096) vblocks = 4096;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define SAGNN_LNB(V)                                                                                              \
+  hipLaunchKernelGGL(layernorm_td_bwd_vec_kernel<V>, dim3((unsigned)vblocks), dim3(kBlock), 0, s, h, ld_h, dy, ld_dy, \
+                     n, t, d, gamma, eps, dh, ld_dh, dgamma, dbeta, lpn)
+    if (vpl <= 1) SAGNN_LNB(1);
+    else if (vpl <= 2) SAGNN_LNB(2);
+    else if (vpl <= 4) SAGNN_LNB(4);
+    else SAGNN_LNB(8);
+#undef SAGNN_LNB
+    SAGNN_HIP_TRY(hipGetLastError());
+    return SAGNN_OK;
+  }
   int64_t blocks = (n + 3) / 4;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(layernorm_td_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0,
