@@ -66,6 +66,27 @@ def test_interval_fusion_vs_oracle(dev, d, t, n):
     np.testing.assert_allclose(got.cpu().numpy(), O.interval_fusion(x, p, 16), rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("d", [32, 64])
+@pytest.mark.parametrize("t", [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 32])
+def test_attention_forms_every_interval_count(dev, d, t):
+    """The attention kernel is specialised on the interval count (pair form for T <= 8, preloaded
+    head-split form for 12 / 16, run-time form otherwise): each form, with and without the fused
+    layer norm, against the oracle; node counts that leave ragged wave tiles."""
+    from sa_gnn_amd import ops
+    rng = np.random.default_rng(1000 * d + t)
+    n = 4 * (32 // t) * 3 + 5
+    x = rng.standard_normal((n, t, d)).astype(np.float32)
+    p, pd = _params(d, rng, dev)
+    xd = torch.from_numpy(x).to(dev)
+    got = ops.mhsa_mean(xd, pd["Wq"], pd["bq"], pd["Wk"], pd["bk"], pd["Wv"], pd["bv"], 16)
+    want = O.mhsa(x, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], 16).mean(axis=1)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+    got = ops.ln_mhsa_mean(xd, pd["ln_gamma"], pd["ln_beta"], pd["Wq"], pd["bq"], pd["Wk"], pd["bk"], pd["Wv"], pd["bv"], 16)
+    y = O.layer_norm_td(x, p["ln_gamma"], p["ln_beta"])
+    want = O.mhsa(y, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], 16).mean(axis=1)
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=RTOL, atol=ATOL)
+
+
 @pytest.mark.parametrize("d", [32, 64, 128])
 def test_fusion_golden(dev, d):
     from sa_gnn_amd import ops
