@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SAGNN_VERSION 10100 /* 1.1.0 */
+#define SAGNN_VERSION 10200 /* 1.2.0 */
 
 enum {
   SAGNN_OK = 0,
@@ -157,6 +157,7 @@ typedef struct sagnn_spmm_epilogue {
   uint8_t* mask_out;
   const uint8_t* mask_in;
   float* out2; int64_t ldo2; float slope2;
+  const float* acc_in2; int64_t ld_acc_in2;   /* optional second addend: acc_out = acc_in + acc_in2 + y */
 } sagnn_spmm_epilogue;
 
 int sagnn_spmm_ex_f32(const sagnn_spmm_plan* plan, const float* X, int64_t ldx, int d,

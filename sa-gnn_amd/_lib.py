@@ -26,7 +26,8 @@ class SpmmEpilogue(ctypes.Structure):
     _fields_ = [("leaky", c_float), ("residual", c_void_p), ("ldr", c_int64), ("out", c_void_p),
                 ("ldo", c_int64), ("acc_in", c_void_p), ("ld_acc_in", c_int64), ("acc_out", c_void_p),
                 ("ld_acc_out", c_int64), ("mask_out", c_void_p), ("mask_in", c_void_p),
-                ("out2", c_void_p), ("ldo2", c_int64), ("slope2", c_float)]
+                ("out2", c_void_p), ("ldo2", c_int64), ("slope2", c_float), ("acc_in2", c_void_p),
+                ("ld_acc_in2", c_int64)]
 
 
 class PlanInfo(ctypes.Structure):

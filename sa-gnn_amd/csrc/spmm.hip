@@ -46,6 +46,8 @@ struct Epilogue {
   int64_t ldo2;
   float slope2;
   int mask_stride;         // bytes per mask row (= lanes per row)
+  const float* acc_in2;    // second addend of the running sum (acc_out = acc_in + acc_in2 + y)
+  int64_t ld_acc_in2;
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) {
@@ -59,7 +61,7 @@ __device__ __forceinline__ void add4(float4& a, const float4& b) {
   a.w += b.w;
 }
 
-// y = max(leaky*s, s) + residual ; out = y ; acc_out = acc_in + y ; training extras as above.
+// y = max(leaky*s, s) + residual ; out = y ; acc_out = acc_in + y (+ acc_in2) ; training extras as above.
 __device__ __forceinline__ void finish_row(const Epilogue& ep, int64_t row, int col, float4 s) {
   float4 y;
   y.x = fmaxf(ep.leaky * s.x, s.x);
@@ -87,6 +89,7 @@ __device__ __forceinline__ void finish_row(const Epilogue& ep, int64_t row, int 
               : ld4(ep.acc_in + row * ep.ld_acc_in + col);
     }
     add4(a, y);
+    if (ep.acc_in2) add4(a, ld4(ep.acc_in2 + row * ep.ld_acc_in2 + col));
     st4(ep.acc_out + row * ep.ld_acc_out + col, a);
     y = a;
   }
@@ -507,6 +510,8 @@ extern "C" int sagnn_spmm_ex_f32(const sagnn_spmm_plan* plan, const float* X, in
   if (int rc = check_mat("out", e->out, e->ldo, d, false)) return rc;
   if (int rc = check_mat("acc_in", e->acc_in, e->ld_acc_in, d, false)) return rc;
   if (int rc = check_mat("acc_out", e->acc_out, e->ld_acc_out, d, false)) return rc;
+  if (int rc = check_mat("acc_in2", e->acc_in2, e->ld_acc_in2, d, false)) return rc;
+  if (e->acc_in2 && !e->acc_out) return sagnn::fail(SAGNN_ERR_ARG, "acc_in2 given without acc_out");
   if (int rc = check_mat("out2", e->out2, e->ldo2, d, false)) return rc;
   if ((e->out && e->out == X) || (e->acc_out && e->acc_out == X) || (e->out2 && e->out2 == X))
     return sagnn::fail(SAGNN_ERR_ARG, "outputs must not alias X");
@@ -521,7 +526,8 @@ extern "C" int sagnn_spmm_ex_f32(const sagnn_spmm_plan* plan, const float* X, in
   if (plan->info.n_rows == 0) return SAGNN_OK;
 
   Epilogue ep{e->residual, e->ldr,       e->acc_in,  e->ld_acc_in, e->out,   e->ldo,    e->acc_out, e->ld_acc_out,
-              e->leaky,    e->mask_out,  e->mask_in, e->out2,      e->ldo2,  e->slope2, d / 4};
+              e->leaky,    e->mask_out,  e->mask_in, e->out2,      e->ldo2,  e->slope2, d / 4,
+              e->acc_in2,  e->ld_acc_in2};
   hipStream_t s = static_cast<hipStream_t>(stream);
   float* partial = static_cast<float*>(workspace);
   switch (sagnn::lanes_per_row(d)) {
@@ -592,15 +598,26 @@ extern "C" int sagnn_gnn_interval_ex_f32(const sagnn_spmm_plan* plan_user, const
     eu.out = last ? nullptr : scratch_u + (int64_t)(l & 1) * U * d;
     ei.out = last ? nullptr : scratch_i + (int64_t)(l & 1) * I * d;
     eu.ldo = ei.ldo = d;
-    // layer 0 seeds the running sum with e^0 (acc_in = residual); later layers add in place.
-    eu.acc_in = (l == 0) ? cu : user_out;
-    eu.ld_acc_in = (l == 0) ? lcu : ld_uo;
-    ei.acc_in = (l == 0) ? ci : item_out;
-    ei.ld_acc_in = (l == 0) ? lci : ld_io;
-    eu.acc_out = user_out;
-    eu.ld_acc_out = ld_uo;
-    ei.acc_out = item_out;
-    ei.ld_acc_out = ld_io;
+    // Running sum sum_l e^l without a write that is only read back: layer 0 of a deeper stack
+    // writes e^1 alone; layer 1 starts the sum from e^1 (its residual, already in registers);
+    // the LAST layer adds e^0 on the way out (acc_in2). One layer: acc_out = e^0 + e^1 directly.
+    const bool sum_here = last || l >= 1;
+    if (sum_here) {
+      eu.acc_in = (l <= 1) ? cu : user_out;
+      eu.ld_acc_in = (l <= 1) ? lcu : ld_uo;
+      ei.acc_in = (l <= 1) ? ci : item_out;
+      ei.ld_acc_in = (l <= 1) ? lci : ld_io;
+      eu.acc_out = user_out;
+      eu.ld_acc_out = ld_uo;
+      ei.acc_out = item_out;
+      ei.ld_acc_out = ld_io;
+      if (last && l >= 1) {
+        eu.acc_in2 = u0;
+        eu.ld_acc_in2 = ld_u0;
+        ei.acc_in2 = i0;
+        ei.ld_acc_in2 = ld_i0;
+      }
+    }
     if (mask_u) {
       eu.mask_out = mask_u + (int64_t)l * U * mrow;
       ei.mask_out = mask_i + (int64_t)l * I * mrow;
