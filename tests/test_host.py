@@ -106,6 +106,20 @@ def test_fusion_argument_errors_without_gpu():
     assert lib.sagnn_interval_fusion_workspace_bytes(10, 3, 128) == 10 * 3 * 128 * 4 + 10 * 3 * 3 * 128 * 4
     assert lib.sagnn_interval_fusion_workspace_bytes(10, 3, 48) == 10 * 3 * 48 * 4
     assert lib.sagnn_layernorm_td_f32(None, 0, 0, 0, 0, 64, None, None, 1e-12, None, 0, None) == -2
+    # training entries: dimension and pointer checks come before any device work
+    assert lib.sagnn_lstm_bwd_supported(64) == 1 and lib.sagnn_lstm_bwd_supported(128) == 0
+    assert lib.sagnn_lstm_bwd_f32(None, 64, 64, None, None, None, None, 128, None, None, None, None, None, 4, 2, 128, None) == -2
+    assert lib.sagnn_lstm_bwd_f32(None, 64, 64, None, None, None, None, 128, None, None, None, None, None, 4, 2, 64, None) == -1
+    assert lib.sagnn_attn_bwd_front_supported(64, 2, 16) == 1
+    assert lib.sagnn_attn_bwd_front_supported(64, 7, 16) == 0 and lib.sagnn_attn_bwd_front_supported(64, 2, 4) == 0
+    assert lib.sagnn_attn_bwd_front_f32(None, 0, 0, 4, 7, 64, 16, None, None, 1e-12, 1, None, None, None, None, None, None,
+                                        None, 64, None, None, None) == -2
+    assert lib.sagnn_attn_bwd_front_f32(None, 0, 0, 4, 2, 64, 16, None, None, 1e-12, 1, None, None, None, None, None, None,
+                                        None, 64, None, None, None) == -1
+    assert lib.sagnn_ln_mhsa_mean_workspace_bytes(10, 3, 64, 16) == 0          # normalised in registers
+    assert lib.sagnn_ln_mhsa_mean_workspace_bytes(10, 3, 128, 16) == 10 * 3 * 128 * 4 + 10 * 3 * 3 * 128 * 4
+    assert lib.sagnn_ln_mhsa_mean_f32(None, 0, 0, 4, 2, 64, 16, None, None, 1e-12, None, None, None, None, None, None,
+                                      None, 64, None, 0, None) == -1
 
 
 def test_params_match_reference_flags():
