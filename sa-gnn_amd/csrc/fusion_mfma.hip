@@ -609,7 +609,11 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
   constexpr int LPR = D / 4;
   constexpr int RPI = kWave / LPR;
   constexpr int NFILL = kRowsPerWave / RPI;
-  constexpr int QS = 3 * D + 4;    // row stride of the per-wave Q|K|V tile (+16 B: rows of one head on distinct banks)
+  // Row stride of the per-wave Q|K|V tile. Head-split forms: +16 B so the rows of one head fall on
+  // distinct banks. Pair forms at D = 64: exactly 3D, so that node strides are multiples of a bank
+  // row and the 16-lane groups of a ds_read_b128 (lanes {0-3, 12-15, 20-27}, ... = heads of two
+  // neighbouring nodes) never meet on a bank (17 % of the LDS cycles were conflicts with 3D + 4).
+  constexpr int QS = (D == 64 && TT >= 1 && TT <= 8) ? 3 * D : 3 * D + 4;
 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Wqf = lds;
