@@ -142,9 +142,16 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
   __syncthreads();
   STAMP_DECL;
 
+  // Gate non-linearities as exp2(fma(acc, k, k*bias)): the bias add, the forget bias and the
+  // log2(e) scaling ride on one fma (VALU work is paid on top of the fp32 MFMAs, not under them).
+  // sigmoid(x) = 1 / (1 + 2^(-x log2e)); tanh(x) = 1 - 2 / (1 + 2^(2x log2e)).
+  constexpr float kL2E = 1.44269504088896340736f;
   float bcol[CT];
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct) bcol[ct] = bias[ct * 32 + cj];
+  for (int ct = 0; ct < CT; ++ct) {
+    const float b = bias[ct * 32 + cj] + ((ct / HT) == 2 ? forget_bias : 0.f);
+    bcol[ct] = ((ct / HT) == 1 ? 2.f * kL2E : -kL2E) * b;   // j gate: tanh; i, f, o: sigmoid
+  }
   const int fr = lane / LPR, fc4 = (lane % LPR) * 4;           // fill: row-in-group, column
 
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -226,12 +233,12 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
       for (int ht = 0; ht < HT; ++ht) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float gi = acc[ht][r] + bcol[ht], gj = acc[HT + ht][r] + bcol[HT + ht];
-          const float gf = acc[2 * HT + ht][r] + bcol[2 * HT + ht], go = acc[3 * HT + ht][r] + bcol[3 * HT + ht];
-          const float si = fast_sigmoid(gi), tj = fast_tanh(gj), sf = fast_sigmoid(gf + forget_bias);
-          const float so = fast_sigmoid(go);
-          const float cn = c[ht][r] * sf + si * tj;
-          const float hn = fast_tanh(cn) * so;
+          const float si = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc[ht][r], -kL2E, bcol[ht])));
+          const float tj = fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc[HT + ht][r], 2.f * kL2E, bcol[HT + ht]))), 1.f);
+          const float sf = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc[2 * HT + ht][r], -kL2E, bcol[2 * HT + ht])));
+          const float so = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc[3 * HT + ht][r], -kL2E, bcol[3 * HT + ht])));
+          const float cn = fmaf(c[ht][r], sf, si * tj);
+          const float hn = fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(cn * (2.f * kL2E))), 1.f) * so;
           c[ht][r] = cn;
           const int row = crow(r, rh_);
           const int col = ht * 32 + cj_;
