@@ -7,7 +7,7 @@
 // weight load: one wave per SIMD, the whole 512-register budget, no block barriers in the loop.
 //
 //   LDS image of a weight matrix ("fragment order"): for k-step kk, half hf, lane l, e in 0..3:
-//       Wf[((kk*HF + hf)*64 + l)*4 + e] = W[2kk + (l>>5)][(4hf + e)*32 + (l&31)]
+//       Wf[((kk*HF + hf)*64 + l)*4 + e] = W[kcol(kk, l>>5)][(4hf + e)*32 + (l&31)]
 //   so the B operands of 4 column tiles arrive with ONE conflict-free ds_read_b128 per lane.
 //   A operands (x_t, h, layer-norm input) are staged per wave in a [32][D] tile whose column is
 //   XOR-swizzled with the row, which makes both the row-major fill and the column-strided
@@ -63,7 +63,43 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // row of C/D register r in lane half rh for a 32x32 MFMA tile (cdna_hip_programming.md §3)
 __device__ __forceinline__ int crow(int r, int rh) { return (r & 3) + 8 * (r >> 2) + 4 * rh; }
 
-// Copies W [K][NC] (row-major, K even, NC a multiple of 128) into fragment order.
+// ---- the per-wave [32][D] staging tile -------------------------------------------------------
+// Rows are filled row-major (coalesced float4 from global, or element-wise from the MFMA C layout)
+// and read back in the A layout, lane = row, as float4: lane (row, kh) takes columns
+// 8q + 4kh .. + 3, the operands of k-steps 4q .. 4q+3. K-STEP ORDER: k-step m = 4q + e therefore
+// multiplies column kcol(m, kh) = 8q + 4kh + e; the weight fragments are laid out to match. The
+// 16-byte slots of a row are XOR-swizzled with the row so that the 16-lane groups of a
+// ds_read_b128 (one row each) and the 32 consecutive columns of an element-wise write all fall
+// on distinct banks.
+__device__ __forceinline__ int kcol(int m, int kh) { return 8 * (m >> 2) + 4 * kh + (m & 3); }
+template <int D>
+__device__ __forceinline__ int tile_slot(int row, int slot) {
+  constexpr int SL = D / 4;                      // slots per row
+  constexpr int RPB = SL >= 16 ? 1 : 16 / SL;    // rows per 256-byte bank row
+  return slot ^ ((row / RPB) & (SL - 1));
+}
+template <int D>
+__device__ __forceinline__ float4* tile_vec(float* tile, int row, int slot) {
+  return reinterpret_cast<float4*>(tile + row * D) + tile_slot<D>(row, slot);
+}
+template <int D>
+__device__ __forceinline__ float* tile_elem(float* tile, int row, int col) {
+  return tile + row * D + (tile_slot<D>(row, col >> 2) << 2) + (col & 3);
+}
+// A operand of all D/2 k-steps for lane (row, kh)
+template <int D>
+__device__ __forceinline__ void read_a_operand(float* tile, int row, int kh, float (&a)[D / 2]) {
+#pragma unroll
+  for (int q = 0; q < D / 8; ++q) {
+    const float4 v = *tile_vec<D>(tile, row, 2 * q + kh);
+    a[4 * q + 0] = v.x;
+    a[4 * q + 1] = v.y;
+    a[4 * q + 2] = v.z;
+    a[4 * q + 3] = v.w;
+  }
+}
+
+// Copies W [K][NC] (row-major, K a multiple of 8, NC a multiple of 128) into fragment order.
 template <int NC>
 __device__ __forceinline__ void load_weight_fragments(float* __restrict__ Wf,
                                                       const float* __restrict__ W, int K) {
@@ -75,7 +111,7 @@ __device__ __forceinline__ void load_weight_fragments(float* __restrict__ Wf,
     const int rest = idx >> 8;
     const int hf = rest % HF;
     const int kk = rest / HF;
-    Wf[idx] = W[(size_t)(2 * kk + (l >> 5)) * NC + (4 * hf + e) * 32 + (l & 31)];
+    Wf[idx] = W[(size_t)kcol(kk, l >> 5) * NC + (4 * hf + e) * 32 + (l & 31)];
   }
 }
 
@@ -198,20 +234,11 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
       // ---- stage x_t through LDS into the A layout --------------------------------------
       float a_x[KS];
 #pragma unroll
-      for (int q = 0; q < NFILL; ++q) {
-        const int r = q * RPI + fr_;
-        const int sw = r & 31;
-        float* dst = stage + r * D;
-        dst[(fc4_ + 0) ^ sw] = xr[q].x;
-        dst[(fc4_ + 1) ^ sw] = xr[q].y;
-        dst[(fc4_ + 2) ^ sw] = xr[q].z;
-        dst[(fc4_ + 3) ^ sw] = xr[q].w;
-      }
+      for (int q = 0; q < NFILL; ++q) *tile_vec<D>(stage, q * RPI + fr_, fc4_ >> 2) = xr[q];
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) a_x[kk] = stage[ai_ * D + ((2 * kk + kh_) ^ ai_)];
+      read_a_operand<D>(stage, ai_, kh_, a_x);
       if (ts + 1 < t) fetch_x(ts + 1);  // in flight under the MFMAs below
       STAMP(0);
 
@@ -242,7 +269,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
           c[ht][r] = cn;
           const int row = crow(r, rh_);
           const int col = ht * 32 + cj_;
-          stage[row * D + (col ^ row)] = hn;  // for the next step's A operand
+          *tile_elem<D>(stage, row, col) = hn;  // for the next step's A operand
           // element (row, ts, col) of an [n, t, D] tensor, in floats from the tile's first row
           const int e_td = (row * t + ts) * D + col;
           if (SAVE) {
@@ -264,10 +291,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (ts + 1 < t) {
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) a_h[kk] = stage[ai_ * D + ((2 * kk + kh_) ^ ai_)];
-      }
+      if (ts + 1 < t) read_a_operand<D>(stage, ai_, kh_, a_h);
       __builtin_amdgcn_wave_barrier();
       STAMP(4);
     }
@@ -586,13 +610,13 @@ __device__ __forceinline__ void attention_heads_ct(const float* __restrict__ qkv
 template <int TM>
 __device__ __forceinline__ void load_square_fragments(float* __restrict__ Wf,
                                                       const float* __restrict__ W, int D) {
-  // Wf[(kk*64 + l)*TM + e] = W[2kk + (l>>5)][e*32 + (l&31)],  kk < D/2
+  // Wf[(kk*64 + l)*TM + e] = W[kcol(kk, l>>5)][e*32 + (l&31)],  kk < D/2
   const int total = D * D;
   for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
     const int e = idx % TM;
     const int l = (idx / TM) & 63;
     const int kk = idx / (TM * 64);
-    Wf[idx] = W[(size_t)(2 * kk + (l >> 5)) * D + e * 32 + (l & 31)];
+    Wf[idx] = W[(size_t)kcol(kk, l >> 5) * D + e * 32 + (l & 31)];
   }
 }
 
@@ -650,8 +674,8 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
   float gam[KS], bet[KS];
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) {
-    gam[kk] = apply_ln ? gamma[2 * kk + kh] : 1.f;
-    bet[kk] = apply_ln ? beta[2 * kk + kh] : 0.f;
+    gam[kk] = apply_ln ? gamma[kcol(kk, kh)] : 1.f;   // a[kk] is column kcol(kk, kh) of the lane's row
+    bet[kk] = apply_ln ? beta[kcol(kk, kh)] : 0.f;
   }
   float bqc[TM], bkc[TM], bvc[TM];
 #pragma unroll
@@ -689,22 +713,13 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
 
     // ---- fill the [32][D] tile: row m = nb*t + ts. xr was fetched one tile ahead -----------
 #pragma unroll
-    for (int q = 0; q < NFILL; ++q) {
-      const int m = q * RPI + fr_;
-      const int sw = m & 31;
-      float* dst = stage + m * D;
-      dst[(fc4_ + 0) ^ sw] = xr[q].x;
-      dst[(fc4_ + 1) ^ sw] = xr[q].y;
-      dst[(fc4_ + 2) ^ sw] = xr[q].z;
-      dst[(fc4_ + 3) ^ sw] = xr[q].w;
-    }
+    for (int q = 0; q < NFILL; ++q) *tile_vec<D>(stage, q * RPI + fr_, fc4_ >> 2) = xr[q];
     fetch_tile(tile + gridDim.x);  // next tile's rows, in flight under this tile's work
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     float a[KS];
-#pragma unroll
-    for (int kk = 0; kk < KS; ++kk) a[kk] = stage[ai_ * D + ((2 * kk + kh_) ^ ai_)];
+    read_a_operand<D>(stage, ai_, kh_, a);
     __builtin_amdgcn_wave_barrier();
 
     STAMP(0);
@@ -741,7 +756,8 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
       // global row node0*t + m
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk) stage[ai_ * D + ((2 * kk + kh_) ^ ai_)] = a[kk];
+      for (int q = 0; q < KS / 4; ++q)
+        *tile_vec<D>(stage, ai_, 2 * q + kh_) = make_float4(a[4 * q], a[4 * q + 1], a[4 * q + 2], a[4 * q + 3]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -751,12 +767,10 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
 #pragma unroll
       for (int q = 0; q < NFILL; ++q) {
         const int m = q * RPI + fr_;
-        const float* src = stage + m * D;
-        const int sw = m & 31;
-        const float y0 = src[(fc4_ + 0) ^ sw], y1 = src[(fc4_ + 1) ^ sw], y2 = src[(fc4_ + 2) ^ sw], y3 = src[(fc4_ + 3) ^ sw];
+        const float4 yv = *tile_vec<D>(stage, m, fc4_ >> 2);
         typedef int i32x4 __attribute__((ext_vector_type(4)));
-        const i32x4 pk = {__builtin_bit_cast(int, y0), __builtin_bit_cast(int, y1), __builtin_bit_cast(int, y2),
-                          __builtin_bit_cast(int, y3)};
+        const i32x4 pk = {__builtin_bit_cast(int, yv.x), __builtin_bit_cast(int, yv.y), __builtin_bit_cast(int, yv.z),
+                          __builtin_bit_cast(int, yv.w)};
         __builtin_amdgcn_raw_buffer_store_b128(pk, rs_y, (m * D + fc4_) * 4, 0, 0);
       }
       __builtin_amdgcn_wave_barrier();  // tile reads done before the Q|K|V tile overwrites it
