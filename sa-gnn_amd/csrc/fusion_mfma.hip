@@ -780,10 +780,10 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
 #pragma unroll
     for (int e = 0; e < TM; ++e)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        aq[e][r] = 0.f;
-        ak[e][r] = 0.f;
-        av[e][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {  // accumulators start at the bias (column = lane in the C layout)
+        aq[e][r] = bqc[e];
+        ak[e][r] = bkc[e];
+        av[e][r] = bvc[e];
       }
     {
       float wq[TM], wk[TM], wv[TM], nq[TM], nk[TM], nv[TM];
@@ -826,9 +826,9 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float* dst = qkv + crow(r, rh_) * QS + e * 32 + cj_;
-        dst[0] = aq[e][r] + bqc[e];
-        dst[D] = ak[e][r] + bkc[e];
-        dst[2 * D] = av[e][r] + bvc[e];
+        dst[0] = aq[e][r];
+        dst[D] = ak[e][r];
+        dst[2 * D] = av[e][r];
       }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
