@@ -83,7 +83,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     import torch.distributed as dist
     from sa_gnn_amd import _lib, ops, synthetic
-    from sa_gnn_amd.parallel import IntervalSharding, RowShardExchange, exchange_to_row_shards, gather_fused
+    from sa_gnn_amd.parallel import (IntervalSharding, RowShardExchange, exchange_to_row_shards,
+                                     fuse_as_rounds_arrive, gather_fused)
 
     rehearsal = world > 1 and a.dist_backend == "gloo"
     if rehearsal:
@@ -158,12 +159,16 @@ def main():
             return
         pending = []
         for x_loc, n_rows, p, ex in ((out_u, U, prm[0], ex_u), (out_i, I, prm[1], ex_i)):
-            x = ex.finish() if overlap else exchange_to_row_shards(x_loc.to(comm_dev), sh, n_rows, mode=a.exchange)
-            x = x.to(dev)
-            need = x.shape[0] * x.shape[1] * d                                   # [T, rows_local, d]
-            if fuse_ws.numel() < need:
-                fuse_ws = torch.empty(need, device=dev)
-            f = ops.interval_fusion(x.permute(1, 0, 2), p, heads, workspace=fuse_ws)
+            if overlap:
+                # LSTM steps of a round run as soon as that round has arrived (state carried between
+                # the calls); only the last round's steps wait for the last transfer
+                f, fuse_ws = fuse_as_rounds_arrive(ex, p, heads, dev, fuse_ws)
+            else:
+                x = exchange_to_row_shards(x_loc.to(comm_dev), sh, n_rows, mode=a.exchange).to(dev)
+                need = x.shape[0] * x.shape[1] * d                               # [T, rows_local, d]
+                if fuse_ws.numel() < need:
+                    fuse_ws = torch.empty(need, device=dev)
+                f = ops.interval_fusion(x.permute(1, 0, 2), p, heads, workspace=fuse_ws)
             pending.append(gather_fused(f.to(comm_dev), sh, n_rows, async_op=True))   # users' gather runs under items' fusion
         state["final"] = [fin().to(dev) for _, fin in pending]
 

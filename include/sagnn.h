@@ -235,6 +235,15 @@ int sagnn_gnn_interval_bwd_f32(const sagnn_spmm_plan* plan_user, const sagnn_spm
 int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
                        const float* b, float forget_bias, const float* drop_scale, float* h,
                        int64_t ld_h, void* stream);
+/* The same recurrence continued from a given state: h_init [n, d] (row stride ld_hi) and c_init
+ * [n, d] (both NULL = zero state, i.e. sagnn_lstm_fwd_f32), c_final [n, d] receives the cell state
+ * after the last step (NULL = not wanted). A sequence cut into consecutive calls is bit-identical
+ * to one call; the multi-GPU pipeline uses this to run the steps of the intervals that have
+ * already arrived while the last exchange round is still in flight. */
+int sagnn_lstm_fwd_state_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
+                             const float* W, const float* b, float forget_bias, const float* drop_scale,
+                             const float* h_init, int64_t ld_hi, const float* c_init, float* h, int64_t ld_h,
+                             float* c_final, void* stream);
 int sagnn_layernorm_td_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
                            const float* gamma, const float* beta, float eps, float* y,
                            int64_t ld_y, void* stream);

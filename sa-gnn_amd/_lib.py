@@ -115,6 +115,8 @@ SIGNATURES = {
                                    c_void_p]),
     "sagnn_lstm_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,
                                    c_float, c_void_p, c_void_p, c_int64, c_void_p]),
+    "sagnn_lstm_fwd_state_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_float,
+                                         c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "sagnn_layernorm_td_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,
                                        c_float, c_void_p, c_int64, c_void_p]),
     "sagnn_mhsa_mean_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p,

@@ -34,7 +34,8 @@ inline int lanes_per_row(int d) {
 bool lstm_mfma_supported(int d);
 int lstm_fwd_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
                   const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
-                  float* gates_out, float* c_out, hipStream_t s);
+                  float* gates_out, float* c_out, const float* h_init, int64_t ld_hi, const float* c_init,
+                  float* c_final, hipStream_t s);
 bool mhsa_mfma_supported(int d, int t, int heads);
 int ln_mhsa_mean_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
                       const float* gamma, const float* beta, float eps, int apply_ln, const float* Wq,

@@ -22,7 +22,8 @@ __global__ void lstm_fwd_valu_kernel(const float* __restrict__ x, int64_t ld_n, 
                                      const float* __restrict__ b, float forget_bias,
                                      const float* __restrict__ drop, float* __restrict__ h_out,
                                      int64_t ld_h, float* __restrict__ gates_out,
-                                     float* __restrict__ c_out) {
+                                     float* __restrict__ c_out, const float* __restrict__ h_init, int64_t ld_hi,
+                                     const float* __restrict__ c_init, float* __restrict__ c_final) {
   extern __shared__ float sm[];  // [rows_per_block][2d]: x_t | h
   constexpr int RPT = kLstmRowsPerThread;
   const int j = threadIdx.x % d;
@@ -34,8 +35,14 @@ __global__ void lstm_fwd_valu_kernel(const float* __restrict__ x, int64_t ld_n, 
 
   float c[RPT];
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) c[r] = 0.f;
-  for (int i = threadIdx.x; i < rows_pb * d; i += blockDim.x) sm[(i / d) * d2 + d + (i % d)] = 0.f;
+  for (int r = 0; r < RPT; ++r) {
+    const int64_t row = row_base + rs * RPT + r;
+    c[r] = (c_init && row < n) ? c_init[row * d + j] : 0.f;   // state to continue from (NULL = zero)
+  }
+  for (int i = threadIdx.x; i < rows_pb * d; i += blockDim.x) {
+    const int64_t row = row_base + i / d;
+    sm[(i / d) * d2 + d + (i % d)] = (h_init && row < n) ? h_init[row * ld_hi + (i % d)] : 0.f;
+  }
 
   const float b_i = b[j], b_j = b[d + j], b_f = b[2 * d + j], b_o = b[3 * d + j];
   for (int ts = 0; ts < t; ++ts) {
@@ -88,6 +95,13 @@ __global__ void lstm_fwd_valu_kernel(const float* __restrict__ x, int64_t ld_n, 
         const int64_t o = row * ld_h + (int64_t)ts * d + j;
         h_out[o] = drop ? hn * drop[row * (int64_t)t * d + (int64_t)ts * d + j] : hn;
       }
+    }
+  }
+  if (c_final) {
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int64_t row = row_base + rs * RPT + r;
+      if (row < n) c_final[row * d + j] = c[r];
     }
   }
 }
@@ -255,7 +269,8 @@ namespace sagnn {
 
 int lstm_fwd_valu(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
                   const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
-                  float* gates_out, float* c_out, hipStream_t s) {
+                  float* gates_out, float* c_out, const float* h_init, int64_t ld_hi, const float* c_init,
+                  float* c_final, hipStream_t s) {
   const int slots = kBlock / d > 0 ? kBlock / d : 1;
   const int threads = slots * d;
   const int rows_pb = slots * kLstmRowsPerThread;
@@ -264,7 +279,7 @@ int lstm_fwd_valu(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, 
   const size_t lds = (size_t)rows_pb * 2 * d * sizeof(float);
   ProfileScope prof(kProfLstm, s, n, t);
   hipLaunchKernelGGL(lstm_fwd_valu_kernel, dim3((unsigned)blocks), dim3(threads), lds, s, x, ld_n, ld_t,
-                     n, t, d, W, b, forget_bias, drop, h, ld_h, gates_out, c_out);
+                     n, t, d, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, h_init, ld_hi, c_init, c_final);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
@@ -347,22 +362,34 @@ extern "C" int sagnn_mhsa_mean_wide_f32(const float* x, int64_t ld_n, int64_t ld
                                static_cast<float*>(workspace), static_cast<hipStream_t>(stream));
 }
 
-extern "C" int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
-                                  const float* W, const float* b, float forget_bias,
-                                  const float* drop_scale, float* h, int64_t ld_h, void* stream) {
+extern "C" int sagnn_lstm_fwd_state_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
+                                        const float* W, const float* b, float forget_bias,
+                                        const float* drop_scale, const float* h_init, int64_t ld_hi,
+                                        const float* c_init, float* h, int64_t ld_h, float* c_final, void* stream) {
   if (int rc = check_dims(n, t, d)) return rc;
   if (!x || !W || !b || !h) return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if ((h_init == nullptr) != (c_init == nullptr)) return sagnn::fail(SAGNN_ERR_NULL, "give both h_init and c_init or neither");
   if (int rc = check_strides(ld_n, ld_t, n, t, d)) return rc;
   if (ld_h < (int64_t)t * d) return sagnn::fail(SAGNN_ERR_ARG, "ld_h smaller than t*d");
+  if (h_init && ld_hi < d) return sagnn::fail(SAGNN_ERR_ARG, "ld_hi smaller than d");
   if (n == 0) return SAGNN_OK;
   // matrix-core path: d = 32 / 64 with 16-byte aligned rows; SAGNN_FUSION=valu forces the
   // VALU formulation (A/B runs)
-  const bool vec_ok = sagnn::aligned16(x) && (ld_n & 3) == 0 && (ld_t & 3) == 0;
+  const bool vec_ok = sagnn::aligned16(x) && (ld_n & 3) == 0 && (ld_t & 3) == 0 &&
+                      (!h_init || (sagnn::aligned16(h_init) && (ld_hi & 3) == 0));
+  hipStream_t s = static_cast<hipStream_t>(stream);
   if (sagnn::lstm_mfma_supported(d) && vec_ok && !sagnn::force_valu())
-    return sagnn::lstm_fwd_mfma(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, nullptr,
-                                nullptr, static_cast<hipStream_t>(stream));
-  return sagnn::lstm_fwd_valu(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, nullptr, nullptr,
-                              static_cast<hipStream_t>(stream));
+    return sagnn::lstm_fwd_mfma(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, nullptr, nullptr, h_init,
+                                ld_hi, c_init, c_final, s);
+  return sagnn::lstm_fwd_valu(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, nullptr, nullptr, h_init,
+                              ld_hi, c_init, c_final, s);
+}
+
+extern "C" int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
+                                  const float* W, const float* b, float forget_bias,
+                                  const float* drop_scale, float* h, int64_t ld_h, void* stream) {
+  return sagnn_lstm_fwd_state_f32(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, nullptr, 0, nullptr, h, ld_h,
+                                  nullptr, stream);
 }
 
 extern "C" int sagnn_layernorm_td_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d,
@@ -523,8 +550,8 @@ extern "C" int sagnn_lstm_fwd_train_f32(const float* x, int64_t ld_n, int64_t ld
   if (n == 0) return SAGNN_OK;
   const bool vec_ok = sagnn::aligned16(x) && (ld_n & 3) == 0 && (ld_t & 3) == 0;
   if (sagnn::lstm_mfma_supported(d) && vec_ok && !sagnn::force_valu())
-    return sagnn::lstm_fwd_mfma(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, gates, cell,
-                                static_cast<hipStream_t>(stream));
-  return sagnn::lstm_fwd_valu(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, gates, cell,
-                              static_cast<hipStream_t>(stream));
+    return sagnn::lstm_fwd_mfma(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, gates, cell, nullptr, 0,
+                                nullptr, nullptr, static_cast<hipStream_t>(stream));
+  return sagnn::lstm_fwd_valu(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, gates, cell, nullptr, 0,
+                              nullptr, nullptr, static_cast<hipStream_t>(stream));
 }

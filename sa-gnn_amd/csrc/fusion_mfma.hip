@@ -156,7 +156,12 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
     const float* __restrict__ x, int64_t ld_n, int64_t ld_t, int64_t n, int t,
     const float* __restrict__ W, const float* __restrict__ bias, float forget_bias,
     const float* __restrict__ drop, float* __restrict__ h_out, int64_t ld_h,
-    float* __restrict__ gates_out, float* __restrict__ c_out, int64_t n_tiles) {
+    float* __restrict__ gates_out, float* __restrict__ c_out, int64_t n_tiles,
+    const float* __restrict__ h_init, int64_t ld_hi, const float* __restrict__ c_init,
+    float* __restrict__ c_final) {
+  // h_init [n, D] (row stride ld_hi) / c_init [n, D]: state to continue from (NULL = zero state);
+  // c_final [n, D]: cell state after the last step (NULL = not wanted). A sequence cut into
+  // consecutive calls gives bit-identical results to one call.
   constexpr int NC = 4 * D;        // gate columns
   constexpr int CT = NC / 32;      // column tiles (8 at D=64)
   constexpr int HF = CT / 4;       // b128 reads per k-step
@@ -199,6 +204,27 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
     for (int ht = 0; ht < HT; ++ht)
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[ht][r] = 0.f;
+    if (h_init) {  // continue from a given state: h through the staging tile into the A layout, c in the C layout
+      const int rows_v = (int)(n - row0 < kRowsPerWave ? n - row0 : kRowsPerWave);
+#pragma unroll
+      for (int q = 0; q < NFILL; ++q) {
+        const int r = q * RPI + fr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows_v) v = *reinterpret_cast<const float4*>(h_init + (row0 + r) * ld_hi + fc4);
+        *tile_vec<D>(stage, r, fc4 >> 2) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      read_a_operand<D>(stage, ai, kh, a_h);
+      __builtin_amdgcn_wave_barrier();
+      const auto rs_ci = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c_init + row0 * D), 0, rows_v * D * 4, 0x00020000);
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          c[ht][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ci, (crow(r, rh) * D + ht * 32 + cj) * 4, 0, 0));
+    }
 
     // Global traffic of the tile goes through buffer descriptors: a wave-uniform base (SALU), 32-bit
     // lane offsets, and rows past n dropped by the hardware range check — the 64-bit per-element
@@ -250,7 +276,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
       mfma_half<KS, HF>(acc, a_x, Wf, 0, lane);
       STAMP(1);
-      if (ts > 0)  // h_0 = 0: the recurrent half contributes nothing at the first step
+      if (ts > 0 || h_init)  // zero initial state: the recurrent half contributes nothing at the first step
         mfma_half<KS, HF>(acc, a_h, Wf, KS, lane);
       STAMP(2);
 
@@ -294,6 +320,14 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_fwd_mfma_kernel(
       if (ts + 1 < t) read_a_operand<D>(stage, ai_, kh_, a_h);
       __builtin_amdgcn_wave_barrier();
       STAMP(4);
+    }
+    if (c_final) {
+      const auto rs_cf = __builtin_amdgcn_make_buffer_rsrc(c_final + row0 * D, 0, rows_valid * D * 4, 0x00020000);
+#pragma unroll
+      for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c[ht][r]), rs_cf, (crow(r, rh) * D + ht * 32 + cj) * 4, 0, 0);
     }
   }
   STAMP_FLUSH;
@@ -889,7 +923,8 @@ bool lstm_mfma_supported(int d) { return d == 32 || d == 64; }
 template <int D, bool SAVE>
 static int launch_lstm_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t,
                             const float* W, const float* b, float forget_bias, const float* drop,
-                            float* h, int64_t ld_h, float* gates_out, float* c_out, hipStream_t s) {
+                            float* h, int64_t ld_h, float* gates_out, float* c_out, const float* h_init,
+                            int64_t ld_hi, const float* c_init, float* c_final, hipStream_t s) {
   const size_t lds = (size_t)(2 * D * 4 * D + 4 * kRowsPerWave * D) * sizeof(float);
   static bool configured = false;
   if (!configured) {
@@ -906,22 +941,26 @@ static int launch_lstm_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t 
   const int64_t blocks = n_tiles < cus ? n_tiles : cus;
   ProfileScope prof(kProfLstm, s, n, t);
   hipLaunchKernelGGL((lstm_fwd_mfma_kernel<D, SAVE>), dim3((unsigned)blocks), dim3(kBlock), lds, s, x, ld_n, ld_t,
-                     n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, n_tiles);
+                     n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, n_tiles, h_init, ld_hi, c_init, c_final);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
 
 int lstm_fwd_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
                   const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
-                  float* gates_out, float* c_out, hipStream_t s) {
+                  float* gates_out, float* c_out, const float* h_init, int64_t ld_hi, const float* c_init,
+                  float* c_final, hipStream_t s) {
   const bool save = gates_out != nullptr;
   // 32-row tiles are addressed with 32-bit byte offsets from a per-tile base
   if (ld_n >= (1 << 24) || ld_h >= (1 << 24) || (int64_t)t * d >= (1 << 20))
     return fail(SAGNN_ERR_ARG, "MFMA LSTM: row strides must stay below 2^24 floats");
-  if (d == 64 && save) return launch_lstm_mfma<64, true>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, s);
-  if (d == 64) return launch_lstm_mfma<64, false>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, nullptr, nullptr, s);
-  if (d == 32 && save) return launch_lstm_mfma<32, true>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, s);
-  if (d == 32) return launch_lstm_mfma<32, false>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, nullptr, nullptr, s);
+#define SAGNN_LSTM_GO(DD, SV) \
+  return launch_lstm_mfma<DD, SV>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, h_init, ld_hi, c_init, c_final, s)
+  if (d == 64 && save) SAGNN_LSTM_GO(64, true);
+  if (d == 64) SAGNN_LSTM_GO(64, false);
+  if (d == 32 && save) SAGNN_LSTM_GO(32, true);
+  if (d == 32) SAGNN_LSTM_GO(32, false);
+#undef SAGNN_LSTM_GO
   return fail(SAGNN_ERR_DIM, "MFMA LSTM supports d = 32 or 64, got %d", d);
 }
 

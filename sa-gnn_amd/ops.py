@@ -241,18 +241,31 @@ def _wide(d: int) -> bool:
 
 
 def lstm_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, forget_bias: float = 1.0,
-             drop_scale: torch.Tensor | None = None, out: torch.Tensor | None = None):
-    """BasicLSTMCell over T (reference model.py:135-146): sagnn_lstm_fwd_f32. x [n, t, d]."""
+             drop_scale: torch.Tensor | None = None, out: torch.Tensor | None = None,
+             h0: torch.Tensor | None = None, c0: torch.Tensor | None = None, c_out: torch.Tensor | None = None):
+    """BasicLSTMCell over T (reference model.py:135-146): sagnn_lstm_fwd_state_f32. x [n, t, d].
+    h0 [n, d] (any row stride) + c0 [n, d]: state to continue from (default: zero state, as the
+    reference); c_out [n, d]: receives the cell state after the last step. Cutting a sequence into
+    consecutive calls gives bit-identical results to one call."""
     n, t, d, ld, ldt = _ntd("x", x)
     if out is None:
         out = torch.empty((n, t, d), dtype=torch.float32, device=x.device)
     _, _, _, ldh, _ = _ntd("out", out, dense_td=True)
     if drop_scale is not None and (not drop_scale.is_contiguous() or drop_scale.shape != x.shape):
         raise ValueError("drop_scale must be contiguous [n, t, d]")
+    if (h0 is None) != (c0 is None):
+        raise ValueError("give both h0 and c0 or neither")
+    ld_hi = 0
+    if h0 is not None:
+        ld_hi = _f32_rows("h0", h0, d, n)
+        if _f32_rows("c0", c0, d, n) != d:
+            raise ValueError("c0 must be contiguous [n, d]")
+    if c_out is not None and _f32_rows("c_out", c_out, d, n) != d:
+        raise ValueError("c_out must be contiguous [n, d]")
     lib = _lib.load()
-    check(lib.sagnn_lstm_fwd_f32(x.data_ptr(), ld, ldt, n, t, d, _vec("W", W, 8 * d * d),
-                                 _vec("b", b, 4 * d), float(forget_bias), _ptr(drop_scale),
-                                 out.data_ptr(), ldh, _stream()))
+    check(lib.sagnn_lstm_fwd_state_f32(x.data_ptr(), ld, ldt, n, t, d, _vec("W", W, 8 * d * d),
+                                       _vec("b", b, 4 * d), float(forget_bias), _ptr(drop_scale), _ptr(h0), ld_hi,
+                                       _ptr(c0), out.data_ptr(), ldh, _ptr(c_out), _stream()))
     return out
 
 

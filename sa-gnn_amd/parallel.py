@@ -126,14 +126,53 @@ class RowShardExchange:
                                    input_split_sizes=in_splits, group=self.group, async_op=True)
         self._work.append(w)
 
+    def wait_round(self, j: int) -> torch.Tensor:
+        """Makes the current stream wait for round j alone and returns its slab
+        x[j*world : j*world + cnt] ([cnt, rows_local, d]): the intervals of round j are consecutive
+        in time, so the interval LSTM can run their steps while later rounds are still in flight."""
+        sh = self.sh
+        while self._posted <= j:                   # rounds this rank never had an interval for
+            self.post(None)
+        if sh.world > 1 and self._work[j] is not None:
+            self._work[j].wait()
+            self._work[j] = None
+        cnt = min(sh.world, sh.T - j * sh.world)
+        return self.x[j * sh.world: j * sh.world + cnt]
+
     def finish(self) -> torch.Tensor:
         while self._posted < self.sh.rounds:       # rounds this rank never had an interval for
             self.post(None)
         for w in self._work:
-            w.wait()
+            if w is not None:
+                w.wait()
         self._work.clear()
         self._posted = 0
         return self.x
+
+
+def fuse_as_rounds_arrive(ex: "RowShardExchange", p: dict, heads: int, device, h_buf: torch.Tensor | None = None):
+    """Row-sharded interval fusion (reference model.py:135-155) pipelined with the exchange: the
+    LSTM steps of round j's intervals run as soon as round j has arrived (state carried across the
+    calls: sagnn_lstm_fwd_state_f32, bit-identical to one call over all T), so only the steps of the
+    LAST round wait for the last transfer; layer norm + attention + mean follow on the whole
+    [rows_local, T, d] block. Returns the fused rows [rows_local, d] on `device`."""
+    from . import ops
+    sh, rows, d = ex.sh, ex.rows_local, ex.d
+    need = rows * sh.T * d
+    if h_buf is None or h_buf.numel() < need:
+        h_buf = torch.empty(max(need, 1), dtype=torch.float32, device=device)
+    h = h_buf[:need].view(rows, sh.T, d)
+    c = torch.empty((rows, d), dtype=torch.float32, device=device)
+    t0 = 0
+    for j in range(sh.rounds):
+        xs = ex.wait_round(j).to(device)                       # [cnt, rows, d]
+        cnt = xs.shape[0]
+        ops.lstm_fwd(xs.permute(1, 0, 2), p["lstm_W"], p["lstm_b"], out=h[:, t0:t0 + cnt, :],
+                     h0=h[:, t0 - 1, :] if j else None, c0=c if j else None,
+                     c_out=c if j + 1 < sh.rounds else None)
+        t0 += cnt
+    ex.finish()                                               # resets the exchange for the next step
+    return ops.ln_mhsa_mean(h, p["ln_gamma"], p["ln_beta"], p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], heads), h_buf
 
 
 def gather_fused(final_local: torch.Tensor, sh: IntervalSharding, n_rows: int, group=None,

@@ -66,6 +66,26 @@ def test_interval_fusion_vs_oracle(dev, d, t, n):
     np.testing.assert_allclose(got.cpu().numpy(), O.interval_fusion(x, p, 16), rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("d,n", [(64, 1000), (32, 333), (128, 77)])
+def test_lstm_continuation_is_bit_identical(dev, d, n):
+    """A sequence cut into consecutive calls (h0 / c0 in, cell state out) equals one call bit for
+    bit — what the multi-GPU pipeline relies on when it runs the steps of the intervals that have
+    arrived while the last exchange round is still in flight. x is a [t, n, d] slab viewed [n, t, d]."""
+    from sa_gnn_amd import ops
+    rng = np.random.default_rng(d + n)
+    t, cut = 7, 3
+    xs = torch.from_numpy(rng.standard_normal((t, n, d)).astype(np.float32)).to(dev)
+    p, pd = _params(d, rng, dev)
+    whole = ops.lstm_fwd(xs.permute(1, 0, 2), pd["lstm_W"], pd["lstm_b"])
+    np.testing.assert_allclose(whole.cpu().numpy(), O.basic_lstm(xs.permute(1, 0, 2).cpu().numpy(), p["lstm_W"], p["lstm_b"], 1.0),
+                               rtol=RTOL, atol=ATOL)
+    h = torch.empty((n, t, d), device=dev)
+    c = torch.empty((n, d), device=dev)
+    ops.lstm_fwd(xs[:cut].permute(1, 0, 2), pd["lstm_W"], pd["lstm_b"], out=h[:, :cut, :], c_out=c)
+    ops.lstm_fwd(xs[cut:].permute(1, 0, 2), pd["lstm_W"], pd["lstm_b"], out=h[:, cut:, :], h0=h[:, cut - 1, :], c0=c, c_out=c)
+    assert torch.equal(h, whole)
+
+
 @pytest.mark.parametrize("d", [32, 64])
 @pytest.mark.parametrize("t", [1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 32])
 def test_attention_forms_every_interval_count(dev, d, t):

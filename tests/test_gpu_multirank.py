@@ -39,3 +39,14 @@ def test_two_ranks_match_single_process():
     assert two["n_gpus"] == 2 and two["config"]["exchange"] == "alltoall"
     assert one["final_abs_mean"] == two["final_abs_mean"]
     assert one["roofline"]["launches"] == 16 and two["roofline"]["launches"] == 8      # rank 0's SpMM launches
+
+
+def test_three_ranks_round_wise_fusion_matches_single_process():
+    """Three ranks, six intervals: two exchange rounds, the LSTM continued across them."""
+    common = ["--steps", "1", "--warmup", "1", "--scale", "0.003", "--no-cpu-baseline"]
+    one = _run([sys.executable, "bench.py", "--intervals-per-gpu", "6"] + common)
+    three = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+                  "--master-addr", "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "3",
+                  "--dist-backend", "gloo"] + common)
+    assert one["config"]["intervals_total"] == three["config"]["intervals_total"] == 6
+    assert one["final_abs_mean"] == three["final_abs_mean"]

@@ -43,6 +43,18 @@ def _worker(rank, world, port, T, mode, q):
             for j in range(local.shape[0]):
                 ex.post(local[j])
             x = ex.finish()
+        elif mode == "roundwise":                                    # consume every round as it arrives
+            ex = RowShardExchange(sh, U, d, torch.device("cpu"))
+            for j in range(local.shape[0]):
+                ex.post(local[j])
+            slabs = [ex.wait_round(j).clone() for j in range(sh.rounds)]
+            assert [s_.shape[0] for s_ in slabs] == [min(world, T - j * world) for j in range(sh.rounds)]
+            x = torch.cat(slabs, 0)
+            assert torch.equal(ex.finish(), x)
+            ex.post(local[0] if local.shape[0] else None)            # the exchange is reusable after finish()
+            for j in range(1, local.shape[0]):
+                ex.post(local[j])
+            assert torch.equal(ex.finish(), x)
         else:
             x = exchange_to_row_shards(local, sh, U, mode=mode)      # [T, rows_local, d]
         lo, hi = sh.row_range(U)
@@ -62,7 +74,7 @@ def _free_port():
 
 @pytest.mark.parametrize("world,T,mode", [(2, 4, "alltoall"), (2, 3, "alltoall"), (3, 4, "alltoall"),
                                           (2, 1, "alltoall"), (2, 3, "allgather"), (2, 3, "incremental"),
-                                          (3, 7, "incremental")])
+                                          (3, 7, "incremental"), (2, 4, "roundwise"), (3, 7, "roundwise"), (2, 1, "roundwise")])
 def test_interval_sharded_pipeline_matches_single_process(world, T, mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
