@@ -83,8 +83,8 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
     import torch.distributed as dist
     from sa_gnn_amd import _lib, ops, synthetic
-    from sa_gnn_amd.parallel import (IntervalSharding, RowShardExchange, exchange_to_row_shards,
-                                     fuse_as_rounds_arrive, gather_fused)
+    from sa_gnn_amd.parallel import (IntervalSharding, RoundFusion, RowShardExchange, exchange_to_row_shards,
+                                     ChunkedGather, gather_fused)
 
     rehearsal = world > 1 and a.dist_backend == "gloo"
     if rehearsal:
@@ -147,6 +147,7 @@ def main():
     comm_dev = torch.device("cpu") if rehearsal else dev          # gloo rehearsal: collectives on host copies
     ex_u = RowShardExchange(sh, U, d, comm_dev) if overlap else None
     ex_i = RowShardExchange(sh, I, d, comm_dev) if overlap else None
+    pipes = [RoundFusion(ex_u, prm[0], heads, dev), RoundFusion(ex_i, prm[1], heads, dev)] if overlap else None
 
     def step():
         nonlocal fuse_ws
@@ -157,18 +158,37 @@ def main():
                 ex_i.post(out_i[j].to(comm_dev))
         if a.stages == "spmm":
             return
+        if overlap:
+            # Fusion pipelined with the exchange: the LSTM steps of a round run as soon as that round
+            # has arrived (both node types' early rounds first, so they cover the last transfers);
+            # the all-gather of the fused users runs under the items' tail, and the items' tail is
+            # cut into two row chunks so the first chunk's all-gather runs under the second's compute.
+            R = sh.rounds
+            for j in range(R - 1):
+                for pp in pipes:
+                    pp.lstm_round(j)
+            fins = []
+            for idx, (pp, n_rows) in enumerate(zip(pipes, (U, I))):
+                rows = pp.ex.rows_local
+                if idx == len(pipes) - 1 and n_rows % world == 0 and rows >= 2:
+                    cg = ChunkedGather(sh, n_rows)
+                    for lo, hi in ((0, rows // 2), (rows // 2, rows)):
+                        pp.lstm_round(R - 1, lo, hi)
+                        cg.post(lo, hi, pp.attention(lo, hi).to(comm_dev))
+                    fins.append(cg.finish)
+                else:
+                    pp.lstm_round(R - 1)
+                    fins.append(gather_fused(pp.attention().to(comm_dev), sh, n_rows, async_op=True)[1])
+                pp.done()
+            state["final"] = [fin().to(dev) for fin in fins]
+            return
         pending = []
-        for x_loc, n_rows, p, ex in ((out_u, U, prm[0], ex_u), (out_i, I, prm[1], ex_i)):
-            if overlap:
-                # LSTM steps of a round run as soon as that round has arrived (state carried between
-                # the calls); only the last round's steps wait for the last transfer
-                f, fuse_ws = fuse_as_rounds_arrive(ex, p, heads, dev, fuse_ws)
-            else:
-                x = exchange_to_row_shards(x_loc.to(comm_dev), sh, n_rows, mode=a.exchange).to(dev)
-                need = x.shape[0] * x.shape[1] * d                               # [T, rows_local, d]
-                if fuse_ws.numel() < need:
-                    fuse_ws = torch.empty(need, device=dev)
-                f = ops.interval_fusion(x.permute(1, 0, 2), p, heads, workspace=fuse_ws)
+        for x_loc, n_rows, p in ((out_u, U, prm[0]), (out_i, I, prm[1])):
+            x = exchange_to_row_shards(x_loc.to(comm_dev), sh, n_rows, mode=a.exchange).to(dev)
+            need = x.shape[0] * x.shape[1] * d                                   # [T, rows_local, d]
+            if fuse_ws.numel() < need:
+                fuse_ws = torch.empty(need, device=dev)
+            f = ops.interval_fusion(x.permute(1, 0, 2), p, heads, workspace=fuse_ws)
             pending.append(gather_fused(f.to(comm_dev), sh, n_rows, async_op=True))   # users' gather runs under items' fusion
         state["final"] = [fin().to(dev) for _, fin in pending]
 

@@ -150,29 +150,80 @@ class RowShardExchange:
         return self.x
 
 
-def fuse_as_rounds_arrive(ex: "RowShardExchange", p: dict, heads: int, device, h_buf: torch.Tensor | None = None):
-    """Row-sharded interval fusion (reference model.py:135-155) pipelined with the exchange: the
-    LSTM steps of round j's intervals run as soon as round j has arrived (state carried across the
-    calls: sagnn_lstm_fwd_state_f32, bit-identical to one call over all T), so only the steps of the
-    LAST round wait for the last transfer; layer norm + attention + mean follow on the whole
-    [rows_local, T, d] block. Returns the fused rows [rows_local, d] on `device`."""
-    from . import ops
-    sh, rows, d = ex.sh, ex.rows_local, ex.d
-    need = rows * sh.T * d
-    if h_buf is None or h_buf.numel() < need:
-        h_buf = torch.empty(max(need, 1), dtype=torch.float32, device=device)
-    h = h_buf[:need].view(rows, sh.T, d)
-    c = torch.empty((rows, d), dtype=torch.float32, device=device)
-    t0 = 0
-    for j in range(sh.rounds):
-        xs = ex.wait_round(j).to(device)                       # [cnt, rows, d]
-        cnt = xs.shape[0]
-        ops.lstm_fwd(xs.permute(1, 0, 2), p["lstm_W"], p["lstm_b"], out=h[:, t0:t0 + cnt, :],
+class RoundFusion:
+    """One node type's row-sharded interval fusion (reference model.py:135-155) pipelined with its
+    exchange. The intervals of exchange round j are consecutive in time, so `lstm_round(j)` runs
+    their LSTM steps as soon as round j has arrived, carrying the state across calls
+    (sagnn_lstm_fwd_state_f32: bit-identical to one call over all T); `attention()` then applies
+    layer norm + attention + mean. Both take an optional row range, so the tail of the pipeline can
+    be cut into row chunks whose all-gathers travel under the next chunk's compute."""
+
+    def __init__(self, ex: "RowShardExchange", p: dict, heads: int, device):
+        self.ex, self.p, self.heads, self.device = ex, p, int(heads), device
+        sh, rows, d = ex.sh, ex.rows_local, ex.d
+        self.h = torch.empty((rows, sh.T, d), dtype=torch.float32, device=device)
+        self.c = torch.empty((rows, d), dtype=torch.float32, device=device)
+
+    def lstm_round(self, j: int, lo: int = 0, hi: int | None = None):
+        from . import ops
+        sh = self.ex.sh
+        hi = self.ex.rows_local if hi is None else hi
+        xs = self.ex.wait_round(j).to(self.device)[:, lo:hi, :]              # [cnt, rows, d]
+        t0, cnt = j * sh.world, xs.shape[0]
+        if hi <= lo or cnt == 0:
+            return
+        h, c = self.h[lo:hi], self.c[lo:hi]
+        ops.lstm_fwd(xs.permute(1, 0, 2), self.p["lstm_W"], self.p["lstm_b"], out=h[:, t0:t0 + cnt, :],
                      h0=h[:, t0 - 1, :] if j else None, c0=c if j else None,
                      c_out=c if j + 1 < sh.rounds else None)
-        t0 += cnt
-    ex.finish()                                               # resets the exchange for the next step
-    return ops.ln_mhsa_mean(h, p["ln_gamma"], p["ln_beta"], p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], heads), h_buf
+
+    def attention(self, lo: int = 0, hi: int | None = None) -> torch.Tensor:
+        from . import ops
+        p = self.p
+        hi = self.ex.rows_local if hi is None else hi
+        return ops.ln_mhsa_mean(self.h[lo:hi], p["ln_gamma"], p["ln_beta"], p["Wq"], p["bq"], p["Wk"], p["bk"],
+                                p["Wv"], p["bv"], self.heads)
+
+    def done(self):
+        self.ex.finish()                                                    # resets the exchange for the next step
+
+
+def fuse_as_rounds_arrive(ex: "RowShardExchange", p: dict, heads: int, device):
+    """RoundFusion in its simplest order: every round's LSTM steps as the round arrives, then the
+    attention; returns the fused rows [rows_local, d]."""
+    rf = RoundFusion(ex, p, heads, device)
+    for j in range(ex.sh.rounds):
+        rf.lstm_round(j)
+    out = rf.attention()
+    rf.done()
+    return out
+
+
+class ChunkedGather:
+    """All-gather of fused rows delivered in row chunks (needs n_rows % world == 0): post(lo, hi,
+    rows [hi-lo, d]) starts that chunk's collective at once (async, on RCCL's stream), so it
+    travels under whatever is computed next; finish() -> [N, d] in global row order."""
+
+    def __init__(self, sh: IntervalSharding, n_rows: int, group=None):
+        if n_rows % sh.world:
+            raise ValueError("ChunkedGather needs equal row shards")
+        self.sh, self.n_rows, self.group, self.works = sh, int(n_rows), group, []
+
+    def post(self, lo: int, hi: int, f: torch.Tensor):
+        buf = torch.empty((self.sh.world * (hi - lo), f.shape[-1]), dtype=f.dtype, device=f.device)
+        w = dist.all_gather_into_tensor(buf, f.contiguous(), group=self.group, async_op=True)
+        self.works.append((lo, hi, buf, w))
+
+    def finish(self) -> torch.Tensor:
+        lo0, hi0, buf0, _ = self.works[0]
+        d = buf0.shape[-1]
+        out = torch.empty((self.n_rows, d), dtype=buf0.dtype, device=buf0.device)
+        view = out.view(self.sh.world, self.n_rows // self.sh.world, d)
+        for lo, hi, buf, w in self.works:
+            w.wait()
+            view[:, lo:hi, :] = buf.view(self.sh.world, hi - lo, d)
+        self.works = []
+        return out
 
 
 def gather_fused(final_local: torch.Tensor, sh: IntervalSharding, n_rows: int, group=None,

@@ -50,3 +50,14 @@ def test_three_ranks_round_wise_fusion_matches_single_process():
                   "--dist-backend", "gloo"] + common)
     assert one["config"]["intervals_total"] == three["config"]["intervals_total"] == 6
     assert one["final_abs_mean"] == three["final_abs_mean"]
+
+
+def test_four_ranks_match_single_process():
+    """Four ranks sharing the GPU, eight intervals (two per rank, as the scaling benchmark runs)."""
+    common = ["--steps", "1", "--warmup", "1", "--scale", "0.002", "--no-cpu-baseline"]
+    one = _run([sys.executable, "bench.py", "--intervals-per-gpu", "8"] + common)
+    four = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                 "--master-addr", "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "4",
+                 "--dist-backend", "gloo"] + common)
+    assert one["config"]["intervals_total"] == four["config"]["intervals_total"] == 8
+    assert one["final_abs_mean"] == four["final_abs_mean"]

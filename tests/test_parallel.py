@@ -13,7 +13,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import selfgnn_oracle as O
-from sa_gnn_amd.parallel import IntervalSharding, RowShardExchange, exchange_to_row_shards, gather_fused
+from sa_gnn_amd.parallel import (ChunkedGather, IntervalSharding, RowShardExchange, exchange_to_row_shards,
+                                 gather_fused)
 
 
 def _problem(T, U, I, d, seed=3):
@@ -103,3 +104,35 @@ def test_sharding_maps():
     assert sorted(k for r in range(8) for k in IntervalSharding(13, 8, r).local_intervals) == list(range(13))
     with pytest.raises(ValueError):
         IntervalSharding(4, 2, 2)
+
+
+def _chunk_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n_rows, d = 12 * world, 5
+        sh = IntervalSharding(world, world, rank)
+        full = torch.arange(n_rows * d, dtype=torch.float32).view(n_rows, d)
+        lo_r, hi_r = sh.row_range(n_rows)
+        mine = full[lo_r:hi_r]
+        cg = ChunkedGather(sh, n_rows)
+        for lo, hi in ((0, 5), (5, 12)):                     # uneven chunks of the local rows
+            cg.post(lo, hi, mine[lo:hi])
+        q.put((rank, torch.equal(cg.finish(), full), torch.equal(gather_fused(mine, sh, n_rows), full)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_chunked_gather_restores_row_order(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p_ in procs:
+        p_.join(60)
+    assert all(ok1 and ok2 for _, ok1, ok2 in res)
