@@ -125,9 +125,11 @@ def test_train_epoch_runs_and_improves_loss(dev):
     args.trnNum, args.lr, args.keepRate, args.ssl_reg, args.reg = 64, 5e-3, 0.5, 1e-3, 1e-4
     args.decay_step = args.trnNum // args.batch
     np.random.seed(0)
+    torch.manual_seed(0)                                   # dropout masks: the run is reproducible
     before = NNs.params["uEmbed"].detach().clone()
-    losses = [rec.trainEpoch()["preLoss"] for _ in range(4)]
-    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    losses = [rec.trainEpoch()["preLoss"] for _ in range(8)]
+    # one 64-user step per epoch with keepRate 0.5: single steps are noisy, the trend is not
+    assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0] and np.mean(losses[-3:]) < np.mean(losses[:3])
     assert float((NNs.params["uEmbed"].detach() - before).abs().max()) > 0
     res = rec.testEpoch()
     assert 0.0 <= res["HR"] <= 1.0 and 0.0 <= res["NDCG"] <= 1.0
