@@ -66,6 +66,22 @@ def test_interval_fusion_vs_oracle(dev, d, t, n):
     np.testing.assert_allclose(got.cpu().numpy(), O.interval_fusion(x, p, 16), rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("d", [32, 64])
+def test_lstm_saturated_gates(dev, d):
+    """Inputs large enough to saturate every gate (|pre-activation| up to a few hundred): the
+    exp2-based sigmoid / tanh of the MFMA kernel must clamp to 0 / 1 / -1 like the oracle, no NaN."""
+    from sa_gnn_amd import ops
+    rng = np.random.default_rng(d)
+    n, t = 257, 4
+    x = (rng.standard_normal((n, t, d)) * 40.0).astype(np.float32)
+    p, pd = _params(d, rng, dev)
+    got = ops.lstm_fwd(torch.from_numpy(x).to(dev), pd["lstm_W"], pd["lstm_b"]).cpu().numpy()
+    assert np.isfinite(got).all()
+    with np.errstate(over="ignore"):
+        want = O.basic_lstm(x, p["lstm_W"], p["lstm_b"], 1.0)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+
+
 @pytest.mark.parametrize("d,n", [(64, 1000), (32, 333), (128, 77)])
 def test_lstm_continuation_is_bit_identical(dev, d, n):
     """A sequence cut into consecutive calls (h0 / c0 in, cell state out) equals one call bit for
