@@ -321,6 +321,13 @@ int sagnn_attn_bwd_front_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t
                              const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv,
                              const float* bv, const float* g_out, int64_t ld_g, float* dqkv, float* y_out,
                              void* stream);
+/* Tail of the attention backward pass in one pass over dQ|dK|dV (d in {32, 64}): y [rows, d] is
+ * OVERWRITTEN with dy = dqkv Wqkv^T; dWqkv [d, 3d] += y^T dqkv and dbqkv [3d] += column sums of dqkv
+ * are accumulated with float atomics (zero them first). Wqkv = [Wq | Wk | Wv] as [d, 3d]. Replaces
+ * sagnn_dense_tn_f32 + sagnn_dense_nn_f32 on the same operands (dqkv read once instead of twice). */
+int sagnn_attn_bwd_tail_supported(int d);
+int sagnn_attn_bwd_tail_f32(float* y, const float* dqkv, int64_t rows, int d, const float* Wqkv, float* dWqkv,
+                            float* dbqkv, void* stream);
 int sagnn_lstm_bwd_supported(int d);
 int sagnn_lstm_bwd_f32(const float* x, int64_t ld_n, int64_t ld_t, const float* h, const float* gates,
                        const float* cell, const float* dh_ext, int64_t ld_dhe, const float* drop_scale,

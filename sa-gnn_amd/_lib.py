@@ -83,6 +83,8 @@ SIGNATURES = {
     "sagnn_attn_bwd_front_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p,
                                          c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "sagnn_attn_bwd_tail_supported": (c_int, [c_int]),
+    "sagnn_attn_bwd_tail_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "sagnn_lstm_bwd_supported": (c_int, [c_int]),
     "sagnn_lstm_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

@@ -147,8 +147,14 @@ class IntervalFusionFn(torch.autograd.Function):
             ops.check(lib.sagnn_attn_bwd_f32(qkv.data_ptr(), g_out.data_ptr(), d, n, t, d, heads, st))
         dWqkv = torch.zeros((d, 3 * d), dtype=torch.float32, device=dev)
         dbqkv = torch.zeros(3 * d, dtype=torch.float32, device=dev)
-        ops.dense_tn(y2, qkv, dWqkv, dbqkv)
-        dy = ops.dense_nn(qkv, Wqkv.t().contiguous(), None, out=y2)                      # reuses y's storage
+        if lib.sagnn_attn_bwd_tail_supported(d) and os.environ.get("SAGNN_ATTN_BWD", "") != "steps":
+            # dW += y^T dQKV, db += colsum dQKV and dy = dQKV W^T (over y) in one pass over dQKV
+            ops.check(lib.sagnn_attn_bwd_tail_f32(y2.data_ptr(), qkv.data_ptr(), n * t, d, Wqkv.data_ptr(),
+                                                  dWqkv.data_ptr(), dbqkv.data_ptr(), st))
+            dy = y2
+        else:
+            ops.dense_tn(y2, qkv, dWqkv, dbqkv)
+            dy = ops.dense_nn(qkv, Wqkv.t().contiguous(), None, out=y2)                  # reuses y's storage
         # ---- layer norm backward (in place on dy) ----------------------------------------------
         dgamma = torch.zeros(d, dtype=torch.float32, device=dev)
         dbeta = torch.zeros(d, dtype=torch.float32, device=dev)
