@@ -884,7 +884,11 @@ __global__ __launch_bounds__(kBlock, 1) void ln_mhsa_mean_mfma_kernel(
       const int rows_ok = (int)(left < rows_used ? left : rows_used);
       const auto rs_q = __builtin_amdgcn_make_buffer_rsrc(dqkv_out + node0 * t * 3 * D, 0, rows_ok * 3 * D * 4, 0x00020000);
       constexpr int V4 = 3 * D / 4;  // float4 per row
-      for (int i = lane; i < rows_used * V4; i += kWave) {
+      // all 32 tile rows, unrolled (reads batch ahead of the stores); rows past rows_ok fall outside
+      // the descriptor and are dropped
+#pragma unroll
+      for (int k = 0; k < kRowsPerWave * V4 / kWave; ++k) {
+        const int i = lane + k * kWave;
         const int m = i / V4, c4 = (i - m * V4) * 4;
         const float4 v = *reinterpret_cast<const float4*>(qkv + m * QS + c4);
         typedef int i32x4 __attribute__((ext_vector_type(4)));
