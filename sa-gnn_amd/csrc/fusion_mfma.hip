@@ -531,16 +531,32 @@ __device__ __forceinline__ void attention_pairs_bwd(float* __restrict__ qkv, int
                                                     float inv_t, int64_t node0, int64_t n,
                                                     const float* __restrict__ g_out, int64_t ld_g) {
   constexpr int H = D / DK;
+  constexpr int PPL = ((kRowsPerWave / T) * H + kWave - 1) / kWave;   // pairs per lane, at most
   typedef float vec __attribute__((ext_vector_type(DK)));
   const int pairs = nb_per_wave * H;
-  for (int p = lane; p < pairs; p += kWave) {
+  // the upstream gradients of ALL my pairs are requested up front: one exposed memory latency per
+  // tile instead of one per pair
+  vec gpre[PPL];
+#pragma unroll
+  for (int it = 0; it < PPL; ++it) {
+    const int p = lane + it * kWave;
+    const int nb = p / H, hd = p - nb * H;
+    const int64_t node = node0 + nb;
+    gpre[it] = (vec)(0.f);
+    if (p < pairs && node < n) gpre[it] = *reinterpret_cast<const vec*>(g_out + node * ld_g + hd * DK);
+  }
+#pragma unroll 1
+  for (int it = 0; it < PPL; ++it) {   // rolled (the body holds 4T vectors); gpre[it] by selects, not scratch
+    const int p = lane + it * kWave;
+    if (p >= pairs) break;
     const int nb = p / H, hd = p - nb * H;
     float* base = qkv + nb * T * QS + hd * DK;
     vec q[T], k[T], v[T], dk[T];
     float ps[T], asum[T];
-    const int64_t node = node0 + nb;
-    vec g = (vec)(0.f);
-    if (node < n) g = *reinterpret_cast<const vec*>(g_out + node * ld_g + hd * DK) * inv_t;
+    vec g = gpre[0];
+#pragma unroll
+    for (int c = 1; c < PPL; ++c) g = (it == c) ? gpre[c] : g;
+    g *= inv_t;
 #pragma unroll
     for (int ts = 0; ts < T; ++ts) {
       q[ts] = *reinterpret_cast<const vec*>(base + ts * QS);
