@@ -40,3 +40,27 @@ def test_dense_tn(dev, n, din, dout):
     torch.testing.assert_close(db.cpu().double(), g.double().sum(0), rtol=1e-4, atol=1e-4)
     ops.dense_tn(x.to(dev), g.to(dev), dW, None)                    # accumulates
     torch.testing.assert_close(dW.cpu().double(), 2 * want, rtol=1e-4, atol=4e-6 * scale + 1e-5)
+
+
+@pytest.mark.parametrize("rows,d", [(1000, 64), (31, 64), (40007, 64), (513, 32), (70001, 32)])
+def test_attn_bwd_tail(dev, rows, d):
+    """sagnn_attn_bwd_tail_f32: dy (over y), dW and db of the three dense layers in one pass over
+    dQ|dK|dV, against float64 matmuls; sizes from one ragged chunk to many chunks per block."""
+    from sa_gnn_amd import _lib, ops
+    lib = _lib.load()
+    gen = torch.Generator(device="cpu").manual_seed(rows + d)
+    y = torch.randn((rows, d), generator=gen)
+    dqkv = torch.randn((rows, 3 * d), generator=gen)
+    W = torch.randn((d, 3 * d), generator=gen) / d ** 0.5
+    yd, gd, Wd = y.to(dev), dqkv.to(dev), W.to(dev)
+    dW = torch.zeros((d, 3 * d), device=dev)
+    db = torch.zeros(3 * d, device=dev)
+    assert lib.sagnn_attn_bwd_tail_supported(d)
+    ops.check(lib.sagnn_attn_bwd_tail_f32(yd.data_ptr(), gd.data_ptr(), rows, d, Wd.data_ptr(), dW.data_ptr(),
+                                          db.data_ptr(), None))
+    want_dy = dqkv.double() @ W.double().T
+    want_dW = y.double().T @ dqkv.double()
+    torch.testing.assert_close(yd.cpu().double(), want_dy, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dW.cpu().double(), want_dW, rtol=1e-4, atol=2e-6 * float(want_dW.abs().max()) + 1e-5)
+    torch.testing.assert_close(db.cpu().double(), dqkv.double().sum(0), rtol=1e-4, atol=2e-4)
+    assert torch.equal(gd.cpu(), dqkv)                                     # dQKV itself is read-only
