@@ -138,7 +138,9 @@ def main():
     out_i = torch.empty((max(t_loc, 1), I, d), device=dev)[:t_loc]
     scr_u = torch.empty((2, U, d), device=dev) if L > 1 else None
     scr_i = torch.empty((2, I, d), device=dev) if L > 1 else None
-    fuse_ws = torch.empty(1, device=dev)
+    # fusion workspace of the non-pipelined path, sized up front (no allocation inside the timed steps)
+    fuse_ws = torch.empty(max(T * max(sh.row_range(U)[1] - sh.row_range(U)[0], sh.row_range(I)[1] - sh.row_range(I)[0]) * d, 1)
+                          if a.stages == "full" and not (world > 1 and a.exchange == "alltoall") else 1, device=dev)
     state = {}
 
     # N > 1: row-shard exchange buffers; round j is posted right after interval j's SpMM stack and
