@@ -196,7 +196,13 @@ int sagnn_gnn_interval_ex_f32(const sagnn_spmm_plan* plan_user, const sagnn_spmm
 /* Backward of the interval stack (what tf.gradients builds for model.py:118-129): given
  * G_u = dL/d user_out, G_i = dL/d item_out and the recorded masks, writes dL/d u0 and dL/d i0.
  * Same SpMM kernel with the roles of the two adjacencies swapped (the reference already holds
- * both, model.py:234-236). scratch_u: [4, U, d] floats, scratch_i: [4, I, d] floats. */
+ * both, model.py:234-236). scratch_u: [4, U, d] floats, scratch_i: [4, I, d] floats.
+ * ADJOINT CONTRACT: plan_user (rows = users) must be the exact transpose, multiplicities included,
+ * of the item-side pattern the forward pass used, and plan_item that of the user-side pattern.
+ * For matrices without duplicated stored entries these are the forward plans themselves; with
+ * duplicates (forward counts one twice, DataHandler.transpose merges it: DataHandler.py:9-11) the
+ * caller passes plans of the exact transposes — the library cannot tell the two cases apart from
+ * the handles, so the host side checks it (sa-gnn_amd/graph.py interval_pair, ops.gnn_interval_bwd). */
 int sagnn_gnn_interval_bwd_f32(const sagnn_spmm_plan* plan_user, const sagnn_spmm_plan* plan_item,
                                const float* G_u, int64_t ld_gu, const float* G_i, int64_t ld_gi, int d,
                                int n_layers, float leaky, const uint8_t* mask_u, const uint8_t* mask_i,
@@ -396,6 +402,15 @@ int sagnn_mul_f32(const float* a, const float* b, float* out, int64_t count, voi
  * The caller applies the staircase decay lr = lr0 * decay^floor(step/decay_step) (model.py:249). */
 int sagnn_adam_step_f32(float* param, const float* grad, float* m, float* v, int64_t count, float lr,
                         float beta1, float beta2, float eps, float l2, int64_t step, void* stream);
+
+/* The same step for n_tensors parameter tensors in ONE launch (one per 48 tensors): host arrays of
+ * device pointers / element counts / per-tensor l2. grads[i] == NULL means a zero gradient: TF's
+ * minimize() differentiates loss + reg*Regularize() (model.py:245-250), so a registered tensor that
+ * no forward op reads (timeEmbed, the dead [d,d] weights of model.py:81) still receives 2*l2*p and
+ * decays under Adam. All pointers 16-byte aligned. */
+int sagnn_adam_multi_f32(int n_tensors, float* const* params, const float* const* grads, float* const* m,
+                         float* const* v, const int64_t* counts, const float* l2, float lr, float beta1,
+                         float beta2, float eps, int64_t step, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense products on the matrix cores (exact fp32), n rows huge, W small:

@@ -11,6 +11,7 @@ import math
 import torch
 
 paramId = 0
+mhsaId = 0                       # MultiHeadSelfAttention instances since reset(): names their variables
 params: dict[str, torch.Tensor] = {}
 regParams: dict[str, torch.Tensor] = {}
 leaky = 0.1                      # reference NNLayers.py:10; model.prepareModel sets it from args
@@ -21,8 +22,9 @@ _generator: torch.Generator | None = None
 def reset(device="cpu", seed: int = 100):
     """Clears the registry (the reference relies on a fresh process per run) and seeds the
     initialiser stream (reference main.py:21-23 seeds everything with 100)."""
-    global paramId, _device, _generator
+    global paramId, mhsaId, _device, _generator
     paramId = 0
+    mhsaId = 0
     params.clear()
     regParams.clear()
     _device = torch.device(device)
@@ -34,6 +36,14 @@ def getParamId():
     global paramId
     paramId += 1
     return paramId
+
+
+def getMhsaId():
+    """Creation-order index of a MultiHeadSelfAttention (TF names them dense, dense_1, ... per graph);
+    restarts with reset() so a rebuilt model gets the names its checkpoint holds."""
+    global mhsaId
+    mhsaId += 1
+    return mhsaId
 
 
 def getParam(name):

@@ -9,15 +9,13 @@ from . import NNLayers as NNs
 
 
 class MultiHeadSelfAttention:
-    _count = 0
 
     def __init__(self, d_model, num_attention_heads):
         assert d_model % num_attention_heads == 0                     # reference attention.py:51
         self.d_model = d_model
         self.num_attention_heads = num_attention_heads
         self.d_k = self.d_v = d_model // num_attention_heads
-        MultiHeadSelfAttention._count += 1
-        tag = "mhsa%d_" % MultiHeadSelfAttention._count
+        tag = "mhsa%d_" % NNs.getMhsaId()
         # tf.layers.dense variables: kernel [d, d] xavier, bias [d] zeros; not L2-regularised
         self.Wq = NNs.defineParam(tag + "q_kernel", [d_model, d_model])
         self.bq = NNs.defineParam(tag + "q_bias", [d_model], initializer="zeros")

@@ -111,6 +111,8 @@ SIGNATURES = {
     "sagnn_mul_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "sagnn_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float,
                                     c_float, c_float, c_int64, c_void_p]),
+    "sagnn_adam_multi_f32": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float,
+                                     c_float, c_float, c_int64, c_void_p]),
     "sagnn_dense_nn_f32": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                    c_int, c_void_p]),
     "sagnn_dense_tn_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,

@@ -248,12 +248,7 @@ template <int D>
 int launch(float* y, const float* dqkv, int64_t rows, const float* W, float* dW, float* db, hipStream_t s) {
   constexpr int WD = 4 * D, NCT = D / 32;
   const size_t lds = ((size_t)2 * kRows * WD + (size_t)2 * (4 - NCT) * 1024) * sizeof(float);   // 80 KB at D = 64
-  static bool configured = false;
-  if (!configured) {
-    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_tail_kernel<D>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_tail_kernel<D>), lds)) return rc;
   const int64_t n_chunks = (rows + kRows - 1) / kRows;
   const int64_t want = 2 * (int64_t)cu_count();
   const int64_t blocks = n_chunks < want ? n_chunks : want;

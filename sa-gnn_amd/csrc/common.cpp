@@ -5,7 +5,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 namespace sagnn {
@@ -35,6 +37,33 @@ int hip_fail(hipError_t e, const char* what) {
 bool force_valu() {
   const char* v = getenv("SAGNN_FUSION");
   return v && strcmp(v, "valu") == 0;
+}
+
+int ensure_dynamic_lds(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, size_t> done;   // (device, kernel) -> limit set there
+  int dev = 0;
+  SAGNN_HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  size_t& have = done[std::make_pair(dev, kernel)];
+  if (bytes <= have) return SAGNN_OK;
+  SAGNN_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  have = bytes;
+  return SAGNN_OK;
+}
+
+int cu_count_current() {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  int& c = cus[dev];
+  if (c == 0) {
+    int v = 0;
+    c = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+  }
+  return c;
 }
 
 // ---- profiler ---------------------------------------------------------------------------------

@@ -30,6 +30,12 @@ inline int lanes_per_row(int d) {
   return lpr;  // 8, 16, 32 or 64 for d <= 256
 }
 
+// Raises a kernel's dynamic-LDS limit to `bytes` on the CURRENT device if it is not already that
+// high there. State is per (device, kernel) behind a mutex: the library may be driven from several
+// threads and devices (include/sagnn.h: reentrant, no global mutable state visible to callers).
+int ensure_dynamic_lds(const void* kernel, size_t bytes);
+int cu_count_current();   // compute units of the current device (256 on MI355X), cached per device
+
 // fusion_mfma.hip
 bool lstm_mfma_supported(int d);
 int lstm_fwd_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,

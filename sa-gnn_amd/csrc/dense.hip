@@ -274,12 +274,7 @@ int launch_nn(const float* X, int64_t ldx, int64_t n, int din, const float* W, i
               float* Y, int64_t ldy, int accumulate, hipStream_t s) {
   const size_t lds = ((size_t)din * CT * 32 + 4 * 32 * 32) * sizeof(float);
   if (lds > 160 * 1024) return sagnn::fail(SAGNN_ERR_DIM, "dense_nn: W %d x %d does not fit LDS", din, CT * 32);
-  static size_t configured = 0;
-  if (lds > configured) {
-    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_nn_kernel<CT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = lds;
-  }
+  if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_nn_kernel<CT>), lds)) return rc;
   const int64_t n_tiles = (n + 127) / 128;
   const int64_t blocks = n_tiles < cu_count() ? n_tiles : cu_count();
   hipLaunchKernelGGL(dense_nn_kernel<CT>, dim3((unsigned)blocks), dim3(kBlock), lds, s, X, ldx, n, din, W, ldw, bias,
@@ -292,12 +287,7 @@ template <int TPW, int RC, int NV>
 int launch_tn_rc(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW,
                  int64_t lddw, float* db, hipStream_t s) {
   const size_t lds = (size_t)2 * RC * (din + dout) * sizeof(float);
-  static size_t configured = 0;
-  if (lds > configured) {
-    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_tn_kernel<TPW, RC, NV>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = lds;
-  }
+  if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&dense_tn_kernel<TPW, RC, NV>), lds)) return rc;
   const int64_t n_chunks = (n + RC - 1) / RC;
   const int64_t want = (int64_t)cu_count() * ((TPW <= 4 && lds <= 72 * 1024) ? 2 : 1);
   const int64_t blocks = n_chunks < want ? n_chunks : want;

@@ -325,12 +325,7 @@ int mhsa_mean_wide(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t,
   while (slots > 1 && (size_t)slots * 3 * t * d * sizeof(float) > 64 * 1024) slots >>= 1;
   const size_t lds = (size_t)slots * 3 * t * d * sizeof(float);
   if (lds > 160 * 1024) return fail(SAGNN_ERR_DIM, "t*d = %d too large for LDS", t * d);
-  static size_t configured = 0;
-  if (lds > configured) {
-    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_mean_from_qkv_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = lds;
-  }
+  if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_mean_from_qkv_kernel), lds)) return rc;
   int64_t blocks = (n + slots - 1) / slots;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(attn_mean_from_qkv_kernel, dim3((unsigned)blocks), dim3(slots * d), lds, s, ws, n, t, d, heads,

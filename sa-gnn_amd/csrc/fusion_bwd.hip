@@ -371,6 +371,67 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   p[i] = pv - lr_t * mv / (sqrtf(vv) + eps);
 }
 
+// One launch for up to kAdamMaxTensors parameter tensors: block b works on elements
+// [b*kAdamChunk, (b+1)*kAdamChunk) of the concatenation; the owning tensor is found by a binary
+// search over the (chunk-aligned) block prefix held in the kernel arguments. g == NULL: zero
+// gradient (a registered tensor that only the L2 term reaches).
+constexpr int kAdamMaxTensors = 48;
+constexpr int kAdamChunk = 1024;   // elements per block (256 threads x float4)
+struct AdamTable {
+  float* p[kAdamMaxTensors];
+  const float* g[kAdamMaxTensors];
+  float* m[kAdamMaxTensors];
+  float* v[kAdamMaxTensors];
+  int64_t block0[kAdamMaxTensors + 1];   // first block of tensor i; [n] = total blocks
+  int64_t count[kAdamMaxTensors];
+  float l2[kAdamMaxTensors];
+  int n;
+};
+
+__device__ __forceinline__ void adam_elem(float& pv, float gv, float& mv, float& vv, float lr_t, float b1, float b2,
+                                          float eps, float l2) {
+  gv += 2.f * l2 * pv;
+  mv = b1 * mv + (1.f - b1) * gv;
+  vv = b2 * vv + (1.f - b2) * gv * gv;
+  pv -= lr_t * mv / (sqrtf(vv) + eps);
+}
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamTable tb, float lr_t, float b1, float b2, float eps) {
+  const int64_t b = blockIdx.x;
+  int lo = 0, hi = tb.n - 1;          // largest i with block0[i] <= b (wave-uniform: stays on the SALU)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tb.block0[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const int64_t base = (b - tb.block0[lo]) * kAdamChunk + (int64_t)threadIdx.x * 4;
+  const int64_t count = tb.count[lo];
+  if (base >= count) return;
+  float* __restrict__ p = tb.p[lo] + base;
+  float* __restrict__ m = tb.m[lo] + base;
+  float* __restrict__ v = tb.v[lo] + base;
+  const float* __restrict__ g = tb.g[lo] ? tb.g[lo] + base : nullptr;
+  const float l2 = tb.l2[lo];
+  if (base + 4 <= count) {            // tensors start 16-byte aligned (checked on the host), chunks keep it
+    float4 pv = *reinterpret_cast<float4*>(p), mv = *reinterpret_cast<float4*>(m), vv = *reinterpret_cast<float4*>(v);
+    const float4 gv = g ? *reinterpret_cast<const float4*>(g) : make_float4(0.f, 0.f, 0.f, 0.f);
+    adam_elem(pv.x, gv.x, mv.x, vv.x, lr_t, b1, b2, eps, l2);
+    adam_elem(pv.y, gv.y, mv.y, vv.y, lr_t, b1, b2, eps, l2);
+    adam_elem(pv.z, gv.z, mv.z, vv.z, lr_t, b1, b2, eps, l2);
+    adam_elem(pv.w, gv.w, mv.w, vv.w, lr_t, b1, b2, eps, l2);
+    *reinterpret_cast<float4*>(p) = pv;
+    *reinterpret_cast<float4*>(m) = mv;
+    *reinterpret_cast<float4*>(v) = vv;
+  } else {
+    for (int e = 0; base + e < count; ++e) {
+      float pv = p[e], mv = m[e], vv = v[e];
+      adam_elem(pv, g ? g[e] : 0.f, mv, vv, lr_t, b1, b2, eps, l2);
+      p[e] = pv;
+      m[e] = mv;
+      v[e] = vv;
+    }
+  }
+}
+
 // out[i] = max(leaky*a[i], a[i]) + b[i]   (b nullable)
 __global__ void leaky_add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                  float leaky, int64_t count) {
@@ -470,6 +531,46 @@ extern "C" int sagnn_adam_step_f32(float* param, const float* grad, float* m, fl
   return SAGNN_OK;
 }
 
+extern "C" int sagnn_adam_multi_f32(int n_tensors, float* const* params, const float* const* grads, float* const* m,
+                                    float* const* v, const int64_t* counts, const float* l2, float lr, float beta1,
+                                    float beta2, float eps, int64_t step, void* stream) {
+  if (n_tensors < 0) return sagnn::fail(SAGNN_ERR_ARG, "n_tensors = %d", n_tensors);
+  if (n_tensors == 0) return SAGNN_OK;
+  if (!params || !grads || !m || !v || !counts || !l2) return sagnn::fail(SAGNN_ERR_NULL, "null table pointer");
+  if (step < 1) return sagnn::fail(SAGNN_ERR_ARG, "step counts from 1");
+  const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
+  for (int i0 = 0; i0 < n_tensors; i0 += kAdamMaxTensors) {
+    AdamTable tb{};
+    int64_t blocks = 0;
+    int k = 0;
+    for (int i = i0; i < n_tensors && k < kAdamMaxTensors; ++i) {
+      if (counts[i] < 0) return sagnn::fail(SAGNN_ERR_ARG, "tensor %d: count = %lld", i, (long long)counts[i]);
+      if (counts[i] == 0) continue;
+      if (!params[i] || !m[i] || !v[i]) return sagnn::fail(SAGNN_ERR_NULL, "tensor %d: null param / m / v", i);
+      if (!sagnn::aligned16(params[i]) || !sagnn::aligned16(m[i]) || !sagnn::aligned16(v[i]) ||
+          (grads[i] && !sagnn::aligned16(grads[i])))
+        return sagnn::fail(SAGNN_ERR_ALIGN, "tensor %d: 16-byte alignment required", i);
+      tb.p[k] = params[i];
+      tb.g[k] = grads[i];
+      tb.m[k] = m[i];
+      tb.v[k] = v[i];
+      tb.count[k] = counts[i];
+      tb.l2[k] = l2[i];
+      tb.block0[k] = blocks;
+      blocks += (counts[i] + kAdamChunk - 1) / kAdamChunk;
+      ++k;
+    }
+    if (k == 0) continue;
+    tb.n = k;
+    tb.block0[k] = blocks;
+    if (blocks > INT32_MAX) return sagnn::fail(SAGNN_ERR_ARG, "grid too large");
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), tb,
+                       (float)lr_t, beta1, beta2, eps);
+    SAGNN_HIP_TRY(hipGetLastError());
+  }
+  return SAGNN_OK;
+}
+
 extern "C" int sagnn_attn_bwd_f32(float* qkv, const float* g_out, int64_t ld_g, int64_t n, int t, int d,
                                   int heads, void* stream) {
   if (n < 0 || t < 1 || t > 64 || d < 4 || d > 256 || (d & 3)) return sagnn::fail(SAGNN_ERR_DIM, "bad n/t/d");
@@ -484,12 +585,7 @@ extern "C" int sagnn_attn_bwd_f32(float* qkv, const float* g_out, int64_t ld_g, 
   while (slots > 1 && slots * per_slot > 64 * 1024) slots >>= 1;
   const size_t lds = slots * per_slot;
   if (lds > 160 * 1024) return sagnn::fail(SAGNN_ERR_DIM, "t*d too large for LDS");
-  static size_t configured = 0;
-  if (lds > configured) {
-    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = lds;
-  }
+  if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_kernel), lds)) return rc;
   int64_t blocks = (n + slots - 1) / slots;
   if (blocks > 16384) blocks = 16384;
   hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)blocks), dim3(slots * d), lds, static_cast<hipStream_t>(stream),

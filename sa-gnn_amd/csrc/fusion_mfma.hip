@@ -946,12 +946,7 @@ static int launch_lstm_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t 
                             float* h, int64_t ld_h, float* gates_out, float* c_out, const float* h_init,
                             int64_t ld_hi, const float* c_init, float* c_final, hipStream_t s) {
   const size_t lds = (size_t)(2 * D * 4 * D + 4 * kRowsPerWave * D) * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
-    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_fwd_mfma_kernel<D, SAVE>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_fwd_mfma_kernel<D, SAVE>), lds)) return rc;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
@@ -997,12 +992,7 @@ static int launch_ln_mhsa_t(const float* x, int64_t ld_n, int64_t ld_t, int64_t 
                             const float* Wv, const float* bv, float* out, int64_t ld_out, const float* g_out,
                             float* dqkv_out, float* y_out, hipStream_t s) {
   const size_t lds = (size_t)(3 * D * D + 4 * kRowsPerWave * (3 * D + 4)) * sizeof(float);
-  static bool configured = false;
-  if (!configured) {
-    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ln_mhsa_mean_mfma_kernel<D, TT, BWD>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&ln_mhsa_mean_mfma_kernel<D, TT, BWD>), lds)) return rc;
   int dev = 0, cus = 256;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;

@@ -410,12 +410,7 @@ int launch(const float* x, int64_t ld_n, int64_t ld_t, const float* h, const flo
   const int64_t blocks = n_chunks < cu_count() ? n_chunks : cu_count();
   const int nq = 4 * D / 8, ql = nq - (D == 64 ? 2 : 0), nw1 = 2 * D / 32;
   const size_t lds = (size_t)kRows * (4 * D + D) * sizeof(float) + (size_t)nw1 * ql * 64 * sizeof(float4);
-  static bool configured = false;
-  if (!configured) {
-    SAGNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_bwd_mfma_kernel<D>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
-  }
+  if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_bwd_mfma_kernel<D>), lds)) return rc;
   hipLaunchKernelGGL(lstm_bwd_mfma_kernel<D>, dim3((unsigned)blocks), dim3(kBlock), lds, s, x, ld_n, ld_t, h, gates,
                      cell, dh_ext, ld_dhe, drop, W, dx, dW, db, n, t, n_chunks);
   SAGNN_HIP_TRY(hipGetLastError());

@@ -59,7 +59,34 @@ class IntervalAdj:
         return cls(rowptr, colidx, mat.shape, device, tuning=tuning)
 
 
+def exact_transpose_arrays(mat):
+    """CSR arrays of the transposed STORED pattern of `mat`, multiplicities kept (a duplicated
+    (u, i) stays two edges) — the adjoint of csr_arrays(mat), unlike DataHandler.transpose."""
+    coo = sp.coo_matrix(mat)
+    n_cols = int(mat.shape[1])
+    order = np.argsort(np.asarray(coo.col, dtype=np.int64), kind="stable")
+    rowptr = np.zeros(n_cols + 1, dtype=np.int64)
+    np.cumsum(np.bincount(np.asarray(coo.col, dtype=np.int64), minlength=n_cols), out=rowptr[1:])
+    return rowptr.astype(np.int32), np.ascontiguousarray(np.asarray(coo.row, dtype=np.int32)[order])
+
+
 def interval_pair(sub_mat, device, tuning=None):
-    """(subAdj[k], subTpAdj[k]) for one interval matrix (reference model.py:230-237)."""
-    return (IntervalAdj.from_scipy(sub_mat, device, tuning),
-            IntervalAdj.from_scipy(transpose(sub_mat), device, tuning))
+    """(subAdj[k], subTpAdj[k]) for one interval matrix (reference model.py:230-237).
+
+    With duplicated stored entries the two patterns are NOT transposes of each other (forward
+    counts a duplicate twice, DataHandler.transpose merges it — DataHandler.py:9-11), so the
+    backward pass cannot reuse the partner as the adjoint the way it does for canonical matrices.
+    The exact adjoints are then built as well and hung on the plans (`partner_adjoint`):
+    d/d e_i of the user-side sum gathers through the forward pattern's true transpose (the
+    duplicate counts twice, as TF's gather gradient does), d/d e_u of the item-side sum through
+    the merged forward pattern."""
+    fwd = IntervalAdj.from_scipy(sub_mat, device, tuning)
+    tp_mat = transpose(sub_mat)
+    tp = IntervalAdj.from_scipy(tp_mat, device, tuning)
+    if fwd.nnz != tp.nnz:
+        U, I = fwd.dense_shape
+        rp, ci = csr_arrays(transpose(tp_mat))                       # (A_tp)^T: rows = users, merged
+        fwd.plan.partner_adjoint = SpmmPlan(rp, ci, U, I, device=device, tuning=tuning)
+        rp, ci = exact_transpose_arrays(sub_mat)                     # (A_fwd)^T: rows = items, duplicates kept
+        tp.plan.partner_adjoint = SpmmPlan(rp, ci, I, U, device=device, tuning=tuning)
+    return fwd, tp

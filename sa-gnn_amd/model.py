@@ -458,8 +458,7 @@ class Recommender:
     def trainEpoch(self):
         """reference model.py:341-382: trnNum users per epoch in batches of args.batch."""
         if getattr(self, "optimizer", None) is None:
-            self.optimizer = ops.Adam(self._trainable(), lr=args.lr, decay=args.decay, decay_step=args.decay_step,
-                                      reg=args.reg, reg_names=set(NNs.regParams))
+            self.optimizer = self._make_optimizer()
         sfIds = np.random.permutation(args.user)[:args.trnNum]
         steps = int(np.ceil(len(sfIds) / args.batch))
         epochLoss = epochPreLoss = 0.0
@@ -482,9 +481,15 @@ class Recommender:
             epochLoss += float(pre.detach()) + reg
         return {"Loss": epochLoss / steps, "preLoss": epochPreLoss / steps}
 
+    def _make_optimizer(self):
+        return ops.Adam(self._trainable(), lr=args.lr, decay=args.decay, decay_step=args.decay_step,
+                        reg=args.reg, reg_names=set(NNs.regParams))
+
     def saveHistory(self, directory="."):
         """reference model.py:512-520: metric history + variables (torch.save instead of a TF
-        checkpoint; same file stems History/<save_path>.his and Models/<save_path>)."""
+        checkpoint; same file stems History/<save_path>.his and Models/<save_path>). tf.train.Saver()
+        saves every global variable, i.e. also Adam's slots and globalStep — kept here under
+        "optimizer" so a resumed run continues the lr staircase and the moments."""
         import os
         import pickle
         if args.epoch == 0:
@@ -493,18 +498,33 @@ class Recommender:
         os.makedirs(os.path.join(directory, "Models"), exist_ok=True)
         with open(os.path.join(directory, "History", args.save_path + ".his"), "wb") as fs:
             pickle.dump(self.metrics, fs)
-        torch.save({k: v.detach().cpu() for k, v in NNs.params.items()}, os.path.join(directory, "Models", args.save_path))
+        state = {"params": {k: v.detach().cpu() for k, v in NNs.params.items()}}
+        if getattr(self, "optimizer", None) is not None:
+            state["optimizer"] = self.optimizer.state_dict()
+        torch.save(state, os.path.join(directory, "Models", args.save_path))
 
     def loadModel(self, directory="."):
-        """reference model.py:522-526."""
+        """reference model.py:522-526. The variable set and every shape must match the model that
+        prepareModel() built (tf.train.Saver.restore raises on a missing or mis-shaped variable)."""
         import os
         import pickle
         state = torch.load(os.path.join(directory, "Models", args.load_model), weights_only=True)
+        saved = state["params"]
+        if set(saved) != set(NNs.params):
+            raise KeyError(f"checkpoint variables differ from the model's: missing {sorted(set(NNs.params) - set(saved))[:4]}, "
+                           f"unexpected {sorted(set(saved) - set(NNs.params))[:4]}")
+        for k, v in saved.items():
+            if tuple(v.shape) != tuple(NNs.params[k].shape):
+                raise ValueError(f"checkpoint variable {k!r}: shape {tuple(v.shape)} != {tuple(NNs.params[k].shape)}")
         with torch.no_grad():
-            for k, v in state.items():
+            for k, v in saved.items():
                 NNs.params[k].copy_(v)
+        if "optimizer" in state:
+            self.optimizer = self._make_optimizer()
+            self.optimizer.load_state_dict(state["optimizer"])
         with open(os.path.join(directory, "History", args.load_model + ".his"), "rb") as fs:
             self.metrics = pickle.load(fs)
+        print("Model Loaded")
 
     # ------------------------------------------------------------------ model construction
     def prepareModel(self):

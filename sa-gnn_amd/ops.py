@@ -80,6 +80,9 @@ class SpmmPlan:
         self.info = info
         self.device = device
         self._ws: dict[int, torch.Tensor] = {}
+        # plan of the partner's exact transpose when the (user, item) pair of an interval is not a
+        # transposed pair (duplicated stored entries, graph.interval_pair); None = the pair is exact
+        self.partner_adjoint: SpmmPlan | None = None
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -186,6 +189,15 @@ def gnn_interval_bwd(plan_user: SpmmPlan, plan_item: SpmmPlan, grad_user_out: to
     recorded masks -> dL/d u0 [U, d], dL/d i0 [I, d]."""
     d = int(grad_user_out.shape[1])
     U, I = plan_user.n_rows, plan_item.n_rows
+    # rows = users gathers through (item-side forward pattern)^T, rows = items through (user-side)^T
+    adj_u, adj_i = plan_user.partner_adjoint, plan_item.partner_adjoint
+    if (adj_u is None) != (adj_i is None):
+        raise ValueError("give the exact adjoint of both plans or of neither")
+    if adj_u is None and plan_user.nnz != plan_item.nnz:
+        raise ValueError(f"plans are not a transposed pair (nnz {plan_user.nnz} vs {plan_item.nnz}: duplicated stored "
+                         "entries?) — build them with graph.interval_pair, which adds the exact adjoints")
+    if adj_u is not None:
+        plan_user, plan_item = adj_u, adj_i
     ld_gu = _f32_rows("grad_user_out", grad_user_out, d, U)
     ld_gi = _f32_rows("grad_item_out", grad_item_out, d, I)
     dev = grad_user_out.device
@@ -382,7 +394,12 @@ def mul(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None):
 
 class Adam:
     """tf.train.AdamOptimizer with the reference's staircase exponential decay and L2 weights
-    (model.py:245-250): state per parameter tensor, one sagnn_adam_step_f32 launch each."""
+    (model.py:245-250): state per parameter tensor, ONE sagnn_adam_multi_f32 launch per step.
+
+    A parameter whose gradient is None still takes the step when it is L2-regularised: TF
+    differentiates loss + reg*Regularize(), so timeEmbed and the dead [d, d] weights of
+    model.py:81 receive 2*reg*w and decay. Un-regularised tensors without a gradient are left
+    alone (TF's minimize skips variables with no gradient)."""
 
     def __init__(self, params: dict, lr: float, decay: float = 1.0, decay_step: int = 1, reg: float = 0.0,
                  reg_names=(), beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8):
@@ -394,18 +411,56 @@ class Adam:
         self.v = {k: torch.zeros_like(v) for k, v in params.items()}
         self.global_step = 0
 
+    def learning_rate(self) -> float:
+        return self.lr0 * self.decay ** (self.global_step // self.decay_step)     # staircase=True
+
     def step(self, grads: dict):
-        lr = self.lr0 * self.decay ** (self.global_step // self.decay_step)     # staircase=True
+        lr = self.learning_rate()
         self.global_step += 1
-        lib = _lib.load()
+        names, keep = [], []
         for k, g in grads.items():
-            if g is None:
+            if g is None and not (k in self.reg_names and self.reg != 0.0):
                 continue
             p = self.params[k]
-            g = g.contiguous()
-            check(lib.sagnn_adam_step_f32(p.data_ptr(), g.data_ptr(), self.m[k].data_ptr(), self.v[k].data_ptr(),
-                                          p.numel(), lr, self.b1, self.b2, self.eps,
-                                          self.reg if k in self.reg_names else 0.0, self.global_step, _stream()))
+            if not p.is_contiguous():
+                raise ValueError(f"parameter {k!r} must be contiguous")
+            if g is not None:
+                g = g.contiguous()
+                if g.numel() != p.numel() or g.dtype != torch.float32:
+                    raise ValueError(f"gradient of {k!r}: expected {p.numel()} float32 elements")
+                keep.append(g)                      # alive until the launch is queued
+            names.append((k, g))
+        n = len(names)
+        if n == 0:
+            return
+        P, G, M, V = ((ctypes.c_void_p * n)() for _ in range(4))
+        C, L2 = (ctypes.c_int64 * n)(), (ctypes.c_float * n)()
+        for i, (k, g) in enumerate(names):
+            p = self.params[k]
+            P[i], G[i], M[i], V[i] = p.data_ptr(), (None if g is None else g.data_ptr()), self.m[k].data_ptr(), self.v[k].data_ptr()
+            C[i], L2[i] = p.numel(), (self.reg if k in self.reg_names else 0.0)
+        check(_lib.load().sagnn_adam_multi_f32(n, P, G, M, V, C, L2, lr, self.b1, self.b2, self.eps, self.global_step,
+                                               _stream()))
+
+    def state_dict(self) -> dict:
+        """Slots and step counter, as tf.train.Saver stores them with the variables (model.py:512-520)."""
+        out = {"global_step": torch.tensor(self.global_step, dtype=torch.int64)}
+        for k in self.params:
+            out["m/" + k] = self.m[k].detach().cpu()
+            out["v/" + k] = self.v[k].detach().cpu()
+        return out
+
+    def load_state_dict(self, state: dict):
+        want = {"global_step"} | {"m/" + k for k in self.params} | {"v/" + k for k in self.params}
+        if set(state) != want:
+            raise KeyError(f"optimizer state keys differ: missing {sorted(want - set(state))[:4]}, "
+                           f"unexpected {sorted(set(state) - want)[:4]}")
+        for k in self.params:
+            for slot, name in ((self.m, "m/"), (self.v, "v/")):
+                if tuple(state[name + k].shape) != tuple(slot[k].shape):
+                    raise ValueError(f"optimizer slot {name + k}: shape {tuple(state[name + k].shape)} != {tuple(slot[k].shape)}")
+                slot[k].copy_(state[name + k])
+        self.global_step = int(state["global_step"])
 
 
 def leaky_add(a: torch.Tensor, b: torch.Tensor | None, leaky: float, out: torch.Tensor | None = None):

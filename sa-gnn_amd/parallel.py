@@ -14,6 +14,14 @@ across intervals, the first cross-interval op is the stack at model.py:131-132. 
 
 `exchange="allgather"` keeps the plain form of step 2 (all-gather of the stacked interval
 outputs, then each rank slices its rows) for comparison.
+
+Fewer intervals than ranks (Amazon T = 5, Gowalla T = 3 on 8 GPUs — SURVEY.md §8e caveat 2): the
+ranks are cut into T consecutive GROUPS, sized in proportion to the intervals' edge counts, and the
+members of a group split the TARGET ROWS of their interval (`SplitIntervalSharding`,
+`SplitIntervalRunner`): every member runs the SpMM of its row slice against the full source table,
+the members all-gather the layer output inside the group before the next layer reads it, and the
+slice of the running sum goes straight into the same all-to-all (sender order = interval order, so
+x [T, rows_r, d] is still received in place). Steps 3 and 4 are unchanged.
 """
 from __future__ import annotations
 
@@ -54,6 +62,125 @@ class IntervalSharding:
         return b[r], b[r + 1]
 
 
+class SplitIntervalSharding(IntervalSharding):
+    """T < world: rank -> (interval, member index) by consecutive groups. Group sizes follow
+    `weights` (edges per interval) by largest remainder, every interval gets at least one rank.
+    Inside a group the target rows of a node type are cut into g equal slices of
+    q = ceil(n_rows / g) rows (the last one shorter): equal slices keep the intra-group all-gather a
+    plain all_gather_into_tensor on a [g*q, d] buffer."""
+
+    def __init__(self, n_intervals: int, world: int, rank: int, weights=None):
+        super().__init__(n_intervals, world, rank)
+        if not (1 <= self.T < self.world):
+            raise ValueError(f"split sharding is for 1 <= T < world, got T={n_intervals}, world={world}")
+        w = [1.0] * self.T if weights is None else [float(v) for v in weights]
+        if len(w) != self.T or min(w) < 0:
+            raise ValueError("weights: one non-negative number per interval")
+        tot = sum(w) or float(self.T)
+        spare = self.world - self.T                         # ranks beyond one per interval
+        ideal = [spare * (v / tot if sum(w) else 1.0 / self.T) for v in w]
+        extra = [int(x) for x in ideal]
+        order = sorted(range(self.T), key=lambda k: (-(ideal[k] - extra[k]), k))
+        for k in order[: spare - sum(extra)]:
+            extra[k] += 1
+        self.group_size = [1 + e for e in extra]
+        self.group_first = [sum(self.group_size[:k]) for k in range(self.T)]
+        self.rounds = 1
+        k = max(i for i in range(self.T) if self.group_first[i] <= self.rank)
+        self.interval, self.member = k, self.rank - self.group_first[k]
+
+    def owner(self, k: int) -> int:
+        return self.group_first[k]                           # first member
+
+    def members(self, k: int):
+        return list(range(self.group_first[k], self.group_first[k] + self.group_size[k]))
+
+    def intervals_of(self, r: int):
+        return [max(i for i in range(self.T) if self.group_first[i] <= r)]
+
+    def slice_rows(self, n_rows: int, k: int | None = None):
+        """q = rows per member slice of interval k (padded length of the group buffer is g*q)."""
+        g = self.group_size[self.interval if k is None else k]
+        return -(-int(n_rows) // g)
+
+    def slice_range(self, n_rows: int, r: int | None = None):
+        """[lo, hi) target rows rank r computes (may be empty for the last members of tiny matrices)."""
+        r = self.rank if r is None else r
+        k = self.intervals_of(r)[0]
+        q = self.slice_rows(n_rows, k)
+        m = r - self.group_first[k]
+        return min(m * q, int(n_rows)), min((m + 1) * q, int(n_rows))
+
+    def exchange_splits(self, n_rows: int):
+        """(input_split_sizes, output_split_sizes) in rows of the ONE all-to-all: what this rank's
+        slice sends to each row shard, and what it receives from each sender's slice."""
+        b = self.row_bounds(n_rows)
+        ov = lambda a0, a1, b0, b1: max(0, min(a1, b1) - max(a0, b0))     # noqa: E731
+        lo, hi = self.slice_range(n_rows)
+        ins = [ov(lo, hi, b[r], b[r + 1]) for r in range(self.world)]
+        mine = (b[self.rank], b[self.rank + 1])
+        outs = [ov(*self.slice_range(n_rows, s), *mine) for s in range(self.world)]
+        return ins, outs
+
+
+def make_sharding(n_intervals: int, world: int, rank: int, weights=None) -> IntervalSharding:
+    """Cyclic interval sharding when every rank gets an interval, group/row-split sharding otherwise."""
+    if 1 <= n_intervals < world:
+        return SplitIntervalSharding(n_intervals, world, rank, weights)
+    return IntervalSharding(n_intervals, world, rank)
+
+
+def csr_row_slice(rowptr, colidx, lo: int, hi: int):
+    """CSR arrays of rows [lo, hi) with all columns (numpy or torch int32 in, same kind out)."""
+    base = int(rowptr[lo])
+    return rowptr[lo:hi + 1] - base, colidx[base:int(rowptr[hi])]
+
+
+class SplitIntervalRunner:
+    """One interval's L-layer stack (reference model.py:118-129) computed by the g members of a
+    group, each on its slice of the target rows.
+
+    spmm(plan, x, leaky, residual=, out=, acc_in=, acc_out=, want_out=) is ops.spmm (tests pass a
+    CPU stand-in: this class is sharding logic, not arithmetic). plan_u / plan_i are plans of THIS
+    member's row slices (csr_row_slice) against the full source tables. After run(), acc_u / acc_i
+    hold the member's slice of sum_l e^l; layer outputs are all-gathered inside the group (L-1 times
+    per node type) because the next layer gathers from every row of the partner table."""
+
+    def __init__(self, sh: SplitIntervalSharding, n_users: int, n_items: int, d: int, device, group=None,
+                 dtype=torch.float32):
+        self.sh, self.U, self.I, self.d, self.group = sh, int(n_users), int(n_items), int(d), group
+        self.g = sh.group_size[sh.interval]
+        self.qu, self.qi = sh.slice_rows(n_users), sh.slice_rows(n_items)
+        self.ru, self.ri = sh.slice_range(n_users), sh.slice_range(n_items)
+        # full-table ping-pong buffers padded to g*q rows; row m*q + j = row j of member m's slice
+        self.buf_u = torch.zeros((2, self.g * self.qu, d), dtype=dtype, device=device)
+        self.buf_i = torch.zeros((2, self.g * self.qi, d), dtype=dtype, device=device)
+        self.acc_u = torch.empty((self.ru[1] - self.ru[0], d), dtype=dtype, device=device)
+        self.acc_i = torch.empty((self.ri[1] - self.ri[0], d), dtype=dtype, device=device)
+
+    def run(self, spmm, plan_u, plan_i, u0: torch.Tensor, i0: torch.Tensor, n_layers: int, leaky: float):
+        sh, m = self.sh, self.sh.member
+        cur_u, cur_i = u0, i0                                  # full [U, d] / [I, d]
+        (lu, hu), (li, hi) = self.ru, self.ri
+        for l in range(n_layers):
+            last = l + 1 == n_layers
+            nu, ni = self.buf_u[l & 1], self.buf_i[l & 1]
+            mine_u = nu[m * self.qu: m * self.qu + (hu - lu)]
+            mine_i = ni[m * self.qi: m * self.qi + (hi - li)]
+            for plan, src, cur, lo, hi_, mine, acc in ((plan_u, cur_i, cur_u, lu, hu, mine_u, self.acc_u),
+                                                       (plan_i, cur_u, cur_i, li, hi, mine_i, self.acc_i)):
+                if hi_ > lo:
+                    spmm(plan, src[: plan.n_src], leaky, residual=cur[lo:hi_], out=None if last else mine,
+                         acc_in=cur[lo:hi_] if l == 0 else acc, acc_out=acc, want_out=not last)
+            if last:
+                break
+            if self.g > 1:                                     # e^{l+1} of every member, in slice order
+                for buf, q in ((nu, self.qu), (ni, self.qi)):
+                    dist.all_gather_into_tensor(buf, buf[m * q:(m + 1) * q].clone(), group=self.group)
+            cur_u, cur_i = nu[: self.U], ni[: self.I]           # g*q >= n_rows and slices are contiguous
+        return self.acc_u, self.acc_i
+
+
 def exchange_to_row_shards(local_out: torch.Tensor, sh: IntervalSharding, n_rows: int, group=None,
                            mode: str = "alltoall") -> torch.Tensor:
     """local_out [T_local, N, d]: this rank's interval outputs in local order (interval
@@ -64,6 +191,15 @@ def exchange_to_row_shards(local_out: torch.Tensor, sh: IntervalSharding, n_rows
     lo, hi = sh.row_range(n_rows)
     x = torch.empty((sh.T, hi - lo, d), dtype=local_out.dtype, device=local_out.device)
     bounds = sh.row_bounds(n_rows)
+    if isinstance(sh, SplitIntervalSharding):
+        # local_out: this member's slice [slice rows, d] of its interval's output. One all-to-all;
+        # senders arrive in rank order = (interval, slice) order = the layout of x.
+        if mode != "alltoall":
+            raise ValueError("split sharding (T < world) exchanges by all-to-all only")
+        ins, outs = sh.exchange_splits(n_rows)
+        dist.all_to_all_single(x.view(sh.T * (hi - lo), d), local_out.reshape(-1, d), output_split_sizes=outs,
+                               input_split_sizes=ins, group=group)
+        return x
     if mode == "alltoall":
         # all_to_all_single per round j: the input is this rank's j-th interval output split by
         # destination row shard; the blocks arrive in sender order s = 0..world-1, i.e. as the
@@ -108,6 +244,7 @@ class RowShardExchange:
         self._empty = torch.empty((0, d), dtype=dtype, device=device)
         self._work = []
         self._posted = 0
+        self._split = sh.exchange_splits(n_rows) if isinstance(sh, SplitIntervalSharding) else None
 
     def post(self, out_j: torch.Tensor | None):
         """out_j [N, d]: this rank's next interval output (None when the rank has no interval in
@@ -116,6 +253,12 @@ class RowShardExchange:
         self._posted += 1
         if sh.world == 1:
             self.x[j].copy_(out_j[self.bounds[0]:self.bounds[1]])
+            return
+        if self._split is not None:           # T < world: out_j is this member's row slice of its interval
+            ins, outs = self._split
+            w = dist.all_to_all_single(self.x.view(sh.T * self.rows_local, self.d), out_j.reshape(-1, self.d),
+                                       output_split_sizes=outs, input_split_sizes=ins, group=self.group, async_op=True)
+            self._work.append(w)
             return
         have = out_j is not None
         cnt = min(sh.world, sh.T - j * sh.world)
@@ -136,6 +279,8 @@ class RowShardExchange:
         if sh.world > 1 and self._work[j] is not None:
             self._work[j].wait()
             self._work[j] = None
+        if self._split is not None:
+            return self.x
         cnt = min(sh.world, sh.T - j * sh.world)
         return self.x[j * sh.world: j * sh.world + cnt]
 

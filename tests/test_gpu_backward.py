@@ -173,3 +173,54 @@ def test_adam_step_matches_tf_formula(dev):
         v = 0.999 * v + 0.001 * gg * gg
         p = p - lr * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step) * m / (np.sqrt(v) + 1e-8)
     np.testing.assert_allclose(params["w"].cpu().numpy(), p, rtol=1e-4, atol=1e-5)
+
+
+def test_gnn_interval_backward_with_duplicated_stored_entries(dev):
+    """A subMat with a duplicated stored (u, i): the forward counts it twice on the user side and once
+    on the item side (DataHandler.transpose merges it, DataHandler.py:9-11), so the two patterns are
+    not transposes of each other and the backward needs the exact adjoints (graph.interval_pair)."""
+    from sa_gnn_amd import graph, ops
+    rng = np.random.default_rng(99)
+    U, I, d, L = 61, 83, 64, 2
+    base = sp.csr_matrix((rng.random((U, I)) < 0.08).astype(np.intc))
+    indptr, indices = base.indptr.copy(), base.indices.copy()
+    # duplicate the first stored entry of rows 3, 10 and 40 (and one of them twice)
+    rows, cols = [], []
+    for r in range(U):
+        cs = list(indices[indptr[r]:indptr[r + 1]])
+        if r in (3, 10, 40) and cs:
+            cs = [cs[0]] * (3 if r == 10 else 2) + cs[1:]
+        rows += [r] * len(cs)
+        cols += cs
+    ptr = np.zeros(U + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows, minlength=U), out=ptr[1:])
+    m = sp.csr_matrix((np.ones(len(cols), dtype=np.intc), np.asarray(cols, dtype=np.int32), ptr), shape=(U, I))
+    adj_idx, tp_idx = O.trans_to_lsts(m)[0], O.trans_to_lsts(O.transpose(m))[0]
+    assert len(adj_idx) > len(tp_idx)                        # the quirk is present
+    u0 = rng.standard_normal((U, d)).astype(np.float32)
+    i0 = rng.standard_normal((I, d)).astype(np.float32)
+    gu = rng.standard_normal((U, d)).astype(np.float32)
+    gi = rng.standard_normal((I, d)).astype(np.float32)
+    tu = torch.tensor(u0, dtype=torch.float64, requires_grad=True)
+    ti = torch.tensor(i0, dtype=torch.float64, requires_grad=True)
+    ou, oi = O.torch_gnn_interval(tu, ti, adj_idx, tp_idx, L, 0.5)
+    ((ou * torch.tensor(gu, dtype=torch.float64)).sum() + (oi * torch.tensor(gi, dtype=torch.float64)).sum()).backward()
+    fwd, tp = graph.interval_pair(m, dev)
+    assert fwd.plan.partner_adjoint is not None and tp.plan.partner_adjoint is not None
+    mask_u = torch.empty((L, U, d // 4), dtype=torch.uint8, device=dev)
+    mask_i = torch.empty((L, I, d // 4), dtype=torch.uint8, device=dev)
+    uo, io = torch.empty((U, d), device=dev), torch.empty((I, d), device=dev)
+    ops.gnn_interval(fwd.plan, tp.plan, torch.from_numpy(u0).to(dev), torch.from_numpy(i0).to(dev), L, 0.5, uo, io,
+                     mask_u=mask_u, mask_i=mask_i)
+    np.testing.assert_allclose(uo.cpu().numpy(), ou.detach().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(io.cpu().numpy(), oi.detach().numpy(), rtol=1e-4, atol=1e-4)
+    du, di = ops.gnn_interval_bwd(fwd.plan, tp.plan, torch.from_numpy(gu).to(dev), torch.from_numpy(gi).to(dev),
+                                  L, 0.5, mask_u, mask_i)
+    scale = max(float(tu.grad.abs().max()), 1.0)
+    np.testing.assert_allclose(du.cpu().numpy(), tu.grad.numpy(), rtol=1e-4, atol=1e-4 * scale)
+    np.testing.assert_allclose(di.cpu().numpy(), ti.grad.numpy(), rtol=1e-4, atol=1e-4 * scale)
+    # a hand-made pair without the adjoints is refused instead of giving silently wrong gradients
+    fwd.plan.partner_adjoint = tp.plan.partner_adjoint = None
+    with pytest.raises(ValueError, match="transposed pair"):
+        ops.gnn_interval_bwd(fwd.plan, tp.plan, torch.from_numpy(gu).to(dev), torch.from_numpy(gi).to(dev), L, 0.5,
+                             mask_u, mask_i)

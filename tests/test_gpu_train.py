@@ -133,3 +133,83 @@ def test_train_epoch_runs_and_improves_loss(dev):
     assert float((NNs.params["uEmbed"].detach() - before).abs().max()) > 0
     res = rec.testEpoch()
     assert 0.0 <= res["HR"] <= 1.0 and 0.0 <= res["NDCG"] <= 1.0
+
+
+def test_checkpoint_round_trip_resumes_identically(dev, tmp_path):
+    """reference model.py:44-46, 512-526: saveHistory -> a fresh Recommender in the same process
+    (a second prepareModel: variable names must come out the same) -> loadModel -> identical
+    testEpoch() metrics, the resumed start epoch of run(), and an identical NEXT training step
+    (Adam moments, bias correction and the lr staircase continue: tf.train.Saver stores the slots
+    and globalStep with the variables)."""
+    rec, handler, NNs, args = _setup(dev, 64, 32, 1)
+    args.keepRate, args.trnNum, args.epoch, args.tstEpoch, args.lr, args.decay = 1.0, 32, 9, 3, 1e-2, 0.8
+    args.decay_step = args.trnNum // args.batch
+    args.save_path, args.load_model = "ckpt_test", None
+    np.random.seed(5)
+    for ep in range(4):                                   # 4 epochs x 2 steps: the staircase has moved
+        rec.makePrint("Train", ep, rec.trainEpoch(), ep % args.tstEpoch == 0)
+        if ep % args.tstEpoch == 0:
+            rec.makePrint("Test", ep, rec.testEpoch(), True)
+    assert rec.optimizer.global_step == 8 and rec.optimizer.learning_rate() < args.lr
+    want = rec.testEpoch()
+    rec.saveHistory(str(tmp_path))
+    saved_step = rec.optimizer.global_step
+    names = sorted(NNs.params)
+    # the step the ORIGINAL model takes next, on a fixed batch
+    state = np.random.get_state()
+    before = {k: v.detach().clone() for k, v in NNs.params.items()}
+    loss_a = rec.trainEpoch()
+    after_a = {k: v.detach().clone() for k, v in NNs.params.items()}
+    assert max(float((after_a[k] - before[k]).abs().max()) for k in before) > 1e-3      # the step is visible
+
+    from sa_gnn_amd.model import Recommender
+    rec2 = Recommender(dev, handler)
+    rec2.prepareModel()                                   # fresh registry, fresh random init
+    assert sorted(NNs.params) == names                    # attention variables keep their names
+    args.load_model = "ckpt_test"
+    rec2.loadModel(str(tmp_path))
+    assert rec2.optimizer.global_step == saved_step
+    assert len(rec2.metrics["TrainLoss"]) * args.tstEpoch - (args.tstEpoch - 1) == 4     # stloc of run()
+    got = rec2.testEpoch()
+    assert got == want
+    np.random.set_state(state)
+    loss_b = rec2.trainEpoch()
+    # weight-gradient sums use float atomics (last-bit run-to-run differences), hence not torch.equal;
+    # a step from reset moments or a restarted staircase would differ by ~lr = 4e-3
+    assert loss_b == pytest.approx(loss_a, rel=1e-5)
+    for k, v in NNs.params.items():
+        torch.testing.assert_close(v.detach(), after_a[k], rtol=1e-4, atol=2e-5, msg=k)
+    # a checkpoint that does not fit the model is refused
+    args.latdim = 32
+    rec3 = Recommender(dev, handler)
+    rec3.prepareModel()
+    with pytest.raises(ValueError, match="shape"):
+        rec3.loadModel(str(tmp_path))
+    args.load_model, args.latdim = None, 64
+
+
+def test_adam_decays_registered_tensors_without_gradient(dev):
+    """timeEmbed and the dead [d, d] weights (model.py:81, :117) get no gradient from the forward
+    ops but are in regParams: minimize(loss + reg*Regularize()) moves them by the L2 term alone.
+    One multi-tensor launch; un-regularised tensors without a gradient stay put."""
+    from sa_gnn_amd import ops
+    rng = np.random.default_rng(4)
+    w0, t0, b0 = (rng.standard_normal(s).astype(np.float32) for s in ((37, 5), (2, 64), (1003,)))
+    params = {"w": torch.from_numpy(w0.copy()).to(dev), "timeEmbed": torch.from_numpy(t0.copy()).to(dev),
+              "bias": torch.from_numpy(b0.copy()).to(dev)}
+    opt = ops.Adam(params, lr=1e-2, decay=0.9, decay_step=2, reg=1e-2, reg_names={"w", "timeEmbed"})
+    ref = {k: [v.astype(np.float64), np.zeros(v.shape), np.zeros(v.shape)] for k, v in (("w", w0), ("timeEmbed", t0))}
+    for step in range(1, 5):
+        g = rng.standard_normal(w0.shape).astype(np.float32)
+        opt.step({"w": torch.from_numpy(g).to(dev), "timeEmbed": None, "bias": None})
+        lr = 1e-2 * 0.9 ** ((step - 1) // 2)
+        for k, grad in (("w", g.astype(np.float64)), ("timeEmbed", 0.0)):
+            p, m, v = ref[k]
+            gg = grad + 2 * 1e-2 * p
+            m[:] = 0.9 * m + 0.1 * gg
+            v[:] = 0.999 * v + 0.001 * gg * gg
+            p -= lr * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step) * m / (np.sqrt(v) + 1e-8)
+    np.testing.assert_allclose(params["w"].cpu().numpy(), ref["w"][0], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(params["timeEmbed"].cpu().numpy(), ref["timeEmbed"][0], rtol=1e-4, atol=1e-6)
+    assert not np.array_equal(params["timeEmbed"].cpu().numpy(), t0)
+    np.testing.assert_array_equal(params["bias"].cpu().numpy(), b0)

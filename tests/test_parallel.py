@@ -136,3 +136,104 @@ def test_chunked_gather_restores_row_order(world):
     for p_ in procs:
         p_.join(60)
     assert all(ok1 and ok2 for _, ok1, ok2 in res)
+
+
+# ---- fewer intervals than ranks: groups of ranks split the target rows of an interval -----------
+class _CpuPlan:
+    def __init__(self, rowptr, colidx, n_rows, n_src):
+        self.n_rows, self.n_src = n_rows, n_src
+        self.mat = sp.csr_matrix((np.ones(len(colidx), np.float32), colidx, rowptr), shape=(n_rows, n_src))
+
+
+def _cpu_spmm(plan, x, leaky, residual=None, out=None, acc_in=None, acc_out=None, want_out=True):
+    """Stand-in with ops.spmm's contract (y = leaky(A x) + residual; out = y; acc_out = acc_in + y)."""
+    s = torch.from_numpy(plan.mat @ x.numpy())
+    y = torch.maximum(leaky * s, s) + residual
+    if out is not None:
+        out.copy_(y)
+    if acc_out is not None:
+        acc_out.copy_(acc_in + y)
+    return out
+
+
+def _split_worker(rank, world, port, T, weights, q):
+    from sa_gnn_amd.graph import csr_arrays, transpose
+    from sa_gnn_amd.parallel import SplitIntervalRunner, SplitIntervalSharding, csr_row_slice, make_sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        U, I, d, L = 23, 17, 16, 3
+        mats, ue, ie, p = _problem(T, U, I, d)
+        sh = make_sharding(T, world, rank, weights)
+        assert isinstance(sh, SplitIntervalSharding) and sh.rounds == 1
+        groups = [dist.new_group(sh.members(k)) for k in range(T)]      # every rank creates every group
+        k = sh.interval
+        assert sh.local_intervals == [k]
+        rp_u, ci_u = csr_arrays(mats[k])
+        rp_i, ci_i = csr_arrays(transpose(mats[k]))
+        (lu, hu), (li, hi) = sh.slice_range(U), sh.slice_range(I)
+        pu = _CpuPlan(*csr_row_slice(rp_u, ci_u, lu, hu), hu - lu, I)
+        pi = _CpuPlan(*csr_row_slice(rp_i, ci_i, li, hi), hi - li, U)
+        run = SplitIntervalRunner(sh, U, I, d, torch.device("cpu"), group=groups[k])
+        acc_u, acc_i = run.run(_cpu_spmm, pu, pi, torch.from_numpy(ue[k]), torch.from_numpy(ie[k]), L, 0.5)
+        res = {}
+        for tag, acc, n_rows in (("u", acc_u, U), ("i", acc_i, I)):
+            ex = RowShardExchange(sh, n_rows, d, torch.device("cpu"))
+            ex.post(acc)
+            x = ex.wait_round(0).clone()
+            assert torch.equal(ex.finish(), x)
+            assert torch.equal(exchange_to_row_shards(acc, sh, n_rows), x)      # blocking form, same splits
+            lo, hi_ = sh.row_range(n_rows)
+            assert x.shape == (T, hi_ - lo, d)
+            fused = O.interval_fusion(x.permute(1, 0, 2).numpy(), p, 4) if hi_ > lo else np.zeros((0, d), np.float32)
+            res[tag] = gather_fused(torch.from_numpy(fused), sh, n_rows).numpy()
+        q.put((rank, res["u"], res["i"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T,weights", [(8, 5, [72280, 78997, 79692, 78096, 45651]), (4, 3, None), (3, 1, None),
+                                             (8, 3, [5, 1, 1])])
+def test_split_interval_groups_match_single_process(world, T, weights):
+    """T < world (Amazon T = 5 / Gowalla T = 3 on 8 GPUs): rank groups split the target rows of an
+    interval, all-gather the layer outputs inside the group, and feed ONE all-to-all; the fused
+    embeddings of both node types must equal the single-process oracle on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_split_worker, args=(r, world, port, T, weights, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mats, ue, ie, p = _problem(T, 23, 17, 16)
+    uv, iv = O.gnn_stack(ue, ie, [O.trans_to_lsts(m)[0] for m in mats],
+                         [O.trans_to_lsts(O.transpose(m))[0] for m in mats], 3, 0.5)
+    want_u, want_i = O.interval_fusion(uv, p, 4), O.interval_fusion(iv, p, 4)
+    for _, got_u, got_i in results:
+        np.testing.assert_allclose(got_u, want_u, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(got_i, want_i, rtol=1e-5, atol=1e-5)
+
+
+def test_split_sharding_maps():
+    from sa_gnn_amd.parallel import SplitIntervalSharding, make_sharding
+    w = [72280, 78997, 79692, 78096, 45651]
+    shs = [SplitIntervalSharding(5, 8, r, w) for r in range(8)]
+    assert shs[0].group_size == [1, 2, 2, 2, 1]                      # the three heaviest intervals get two ranks
+    assert [s.interval for s in shs] == [0, 1, 1, 2, 2, 3, 3, 4] and [s.member for s in shs] == [0, 0, 1, 0, 1, 0, 1, 0]
+    for n_rows in (11199, 30821, 7, 1):
+        for k in range(5):                                           # member slices tile [0, n_rows)
+            cuts = [shs[r].slice_range(n_rows) for r in shs[0].members(k)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n_rows and all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        tot_in = sum(sum(s.exchange_splits(n_rows)[0]) for s in shs)
+        tot_out = sum(sum(s.exchange_splits(n_rows)[1]) for s in shs)
+        assert tot_in == tot_out == 5 * n_rows
+        for r in range(8):                                           # what r receives from s = what s sends to r
+            assert shs[r].exchange_splits(n_rows)[1] == [shs[s].exchange_splits(n_rows)[0][r] for s in range(8)]
+    assert type(make_sharding(16, 8, 0)) is IntervalSharding and type(make_sharding(8, 8, 0)) is IntervalSharding
+    assert SplitIntervalSharding(3, 8, 0, None).group_size == [3, 3, 2]
+    with pytest.raises(ValueError):
+        SplitIntervalSharding(8, 8, 0)
