@@ -39,6 +39,11 @@ bool force_valu() {
   return v && strcmp(v, "valu") == 0;
 }
 
+bool force_f32_mfma() {
+  const char* v = getenv("SAGNN_GEMM");
+  return v && strcmp(v, "f32") == 0;
+}
+
 int ensure_dynamic_lds(const void* kernel, size_t bytes) {
   static std::mutex mu;
   static std::map<std::pair<int, const void*>, size_t> done;   // (device, kernel) -> limit set there

@@ -1,0 +1,306 @@
+// Interval LSTM on the bf16 matrix cores with fp32-exact operands (gfx950).
+//
+// TF 1.14 BasicLSTMCell over T steps (reference model.py:135-146): gates = [x_t | h] @ W[2d,4d] + b,
+// i, j, f, o = split(gates); c' = c sigmoid(f + fb) + sigmoid(i) tanh(j); h' = tanh(c') sigmoid(o).
+//
+// Why not the f32 MFMA of fusion_mfma.hip: v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate
+// (64 FLOP/clk/SIMD, 1/16 of bf16) and the gate math is paid on top of it. Here every
+// fp32 operand is cut EXACTLY into three bf16 pieces (x = x1 + x2 + x3: 8 + 8 + 8 significand
+// bits, by masking, no rounding) and the product is evaluated as the six largest of the nine
+// piece products,
+//     a b ~ a3 b1 + a1 b3 + a2 b2 + a2 b1 + a1 b2 + a1 b1,
+// each a v_mfma_f32_16x16x32_bf16 (bf16 x bf16 is exact in fp32, accumulation is fp32). Dropped:
+// a2 b3 + a3 b2 + a3 b3 < 2^-20 |a b| — below the rounding an fp32 dot product of this length
+// carries anyway (measured against a float64 product: max error 0.25x that of an fmaf chain).
+// Six bf16 MFMAs cost 6/16 of one fp32 MFMA, and VALU work issues beside bf16 MFMAs.
+//
+// Decomposition (transposed product, gates^T = W^T [x|h]^T): a workgroup of NW = d/16 waves owns
+// 128 rows; wave w owns hidden units 16w .. 16w+15 of all four gates. Its slice of W stays in
+// REGISTERS for the whole kernel as ready-made A fragments (4 gates x 2d/32 k-steps x 3 pieces).
+// x_t and h are shared through LDS as three bf16 images [128][d] each (B fragments: one
+// ds_read_b128 per lane, 16-byte slots XOR-swizzled with the row so reads and writes are
+// conflict-free). In the 16x16 C tile a lane holds 4 consecutive hidden units of ONE row, for all
+// four gates: the gate math needs no cross-lane traffic, h leaves as 16-byte stores, and its three
+// pieces go back to LDS as 8-byte writes. h is double-buffered in LDS, x single (its next step is
+// prefetched into registers): two workgroup barriers per step.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kRows = 128;  // rows per workgroup tile
+constexpr int kBT = 8;      // batch tiles of 16 rows
+
+// x = p1 + p2 + p3 exactly, each piece a bf16 value held in the top 16 bits of a float.
+struct Pieces {
+  float p1, p2, p3;
+};
+__device__ __forceinline__ Pieces split3(float x) {
+  Pieces s;
+  s.p1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u);
+  const float r = x - s.p1;  // exact: the low 16 significand bits
+  s.p2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r) & 0xFFFF0000u);
+  s.p3 = r - s.p2;           // at most 8 significant bits: already a bf16 value
+  return s;
+}
+// bf16 pair (lo element first) from the top halves of two floats
+__device__ __forceinline__ int pack_hi(float lo, float hi) {
+  return (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
+}
+
+// 16-byte slot swizzle of the [row][D] bf16 images. D = 64: 128-byte rows, two rows per 64-bank
+// line -> xor with (row >> 1) & 7. D = 32: 64-byte rows, four rows per line -> xor with a
+// permutation of (row >> 2) & 3 chosen so the mixed lane groups of ds_read_b128
+// ({0-3, 12-15, 20-27}: rows 0-3 and 12-15 of k-group a, rows 4-11 of k-group a+1) stay disjoint.
+template <int D>
+__device__ __forceinline__ int swz(int row) {
+  if (D == 64) return (row >> 1) & 7;
+  const int g = (row >> 2) & 3;       // f = {0, 2, 3, 1}
+  return (0x78 >> (2 * g)) & 3;       // 0b01'11'10'00 read from the low end: g=0 -> 0, 1 -> 2, 2 -> 3, 3 -> 1
+}
+
+__device__ __forceinline__ void lds_barrier() {
+  // LDS traffic only: outstanding global loads (the x prefetch) and stores stay in flight across it
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int D, bool SAVE>
+__global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
+    const float* __restrict__ x, int64_t ld_n, int64_t ld_t, int64_t n, int t, const float* __restrict__ W,
+    const float* __restrict__ bias, float forget_bias, const float* __restrict__ drop, float* __restrict__ h_out,
+    int64_t ld_h, float* __restrict__ gates_out, float* __restrict__ c_out, int64_t n_tiles,
+    const float* __restrict__ h_init, int64_t ld_hi, const float* __restrict__ c_init, float* __restrict__ c_final) {
+  constexpr int NW = D / 16;          // waves per workgroup
+  constexpr int NT = 64 * NW;         // threads
+  constexpr int KSH = D / 32;         // k-steps (of 32) per operand half
+  constexpr int KS = 2 * KSH;
+  constexpr int NC = 4 * D;
+  constexpr int PLANE = kRows * D * 2;          // bytes of one bf16 image
+  constexpr int LPR = D / 4;                    // threads per row in the fill (float4 each)
+  constexpr int RPP = NT / LPR;                 // rows per fill pass (16)
+  constexpr int NFILL = kRows / RPP;            // 8
+  constexpr float kL2E = 1.44269504088896340736f;
+
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const Xp = lds;                         // 3 images
+  char* const Hp = lds + 3 * PLANE;             // 2 x 3 images
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, q = lane >> 4;
+  const int hid0 = 16 * wave + 4 * q;           // first of this lane's 4 hidden units (C rows 4q + r)
+  const int fr = tid / LPR, fc4 = (tid % LPR) * 4;
+
+  // ---- this wave's W slice as A fragments: A[mm = lane & 15][k = 32 ks + 8 q + j] = W[k][g D + 16 wave + mm]
+  i32x4 wf[4][KS][3];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      Pieces pc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pc[j] = split3(W[(size_t)(32 * ks + 8 * q + j) * NC + g * D + 16 * wave + m]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        wf[g][ks][0][e] = pack_hi(pc[2 * e].p1, pc[2 * e + 1].p1);
+        wf[g][ks][1][e] = pack_hi(pc[2 * e].p2, pc[2 * e + 1].p2);
+        wf[g][ks][2][e] = pack_hi(pc[2 * e].p3, pc[2 * e + 1].p3);
+      }
+    }
+  // gate non-linearities as exp2(fma(acc, k, k * bias)): bias, forget bias and log2(e) ride on one fma
+  float bc[4][4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float b = bias[g * D + hid0 + r] + (g == 2 ? forget_bias : 0.f);
+      bc[g][r] = (g == 1 ? 2.f * kL2E : -kL2E) * b;
+    }
+
+  // one [row][4 floats] piece set -> three 8-byte LDS writes
+  auto write_pieces = [&](char* img, int row, int col4, float4 v) {
+    const Pieces a = split3(v.x), b = split3(v.y), c = split3(v.z), d = split3(v.w);
+    const int off = row * (D * 2) + ((((col4 >> 3)) ^ swz<D>(row)) << 4) + ((col4 >> 2) & 1) * 8;
+    *reinterpret_cast<i32x2*>(img + off) = i32x2{pack_hi(a.p1, b.p1), pack_hi(c.p1, d.p1)};
+    *reinterpret_cast<i32x2*>(img + PLANE + off) = i32x2{pack_hi(a.p2, b.p2), pack_hi(c.p2, d.p2)};
+    *reinterpret_cast<i32x2*>(img + 2 * PLANE + off) = i32x2{pack_hi(a.p3, b.p3), pack_hi(c.p3, d.p3)};
+  };
+
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * kRows;
+    const int rows_valid = (int)(n - row0 < kRows ? n - row0 : kRows);
+    float4 xr[NFILL];
+    auto fetch_x = [&](int ts) {
+#pragma unroll
+      for (int p = 0; p < NFILL; ++p) {
+        const int r = p * RPP + fr;
+        xr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows_valid) xr[p] = *reinterpret_cast<const float4*>(x + (row0 + r) * ld_n + (int64_t)ts * ld_t + fc4);
+      }
+    };
+    auto write_x = [&]() {
+#pragma unroll
+      for (int p = 0; p < NFILL; ++p) write_pieces(Xp, p * RPP + fr, fc4, xr[p]);
+    };
+    fetch_x(0);
+
+    // rows past n are dropped by the descriptors' range check
+    const auto rs_h = __builtin_amdgcn_make_buffer_rsrc(h_out + row0 * ld_h, 0, rows_valid * (int)ld_h * 4, 0x00020000);
+    const auto rs_g = __builtin_amdgcn_make_buffer_rsrc(SAVE ? gates_out + row0 * t * NC : h_out, 0,
+                                                        SAVE ? rows_valid * t * NC * 4 : 0, 0x00020000);
+    const auto rs_c = __builtin_amdgcn_make_buffer_rsrc(SAVE ? c_out + row0 * t * D : h_out, 0,
+                                                        SAVE ? rows_valid * t * D * 4 : 0, 0x00020000);
+    const auto rs_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(drop ? drop + row0 * t * D : x), 0,
+                                                        drop ? rows_valid * t * D * 4 : 0, 0x00020000);
+    const auto rs_ci = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c_init ? c_init + row0 * D : x), 0,
+                                                         c_init ? rows_valid * D * 4 : 0, 0x00020000);
+    const auto rs_cf = __builtin_amdgcn_make_buffer_rsrc(c_final ? c_final + row0 * D : h_out, 0,
+                                                         c_final ? rows_valid * D * 4 : 0, 0x00020000);
+
+    f32x4 c[kBT];
+#pragma unroll
+    for (int bt = 0; bt < kBT; ++bt) {
+      c[bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (h_init) c[bt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ci, ((bt * 16 + m) * D + hid0) * 4, 0, 0));
+    }
+    if (h_init) {  // continue from a given state: its pieces are step 0's recurrent operand (buffer 0)
+#pragma unroll
+      for (int p = 0; p < NFILL; ++p) {
+        const int r = p * RPP + fr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows_valid) v = *reinterpret_cast<const float4*>(h_init + (row0 + r) * ld_hi + fc4);
+        write_pieces(Hp, r, fc4, v);
+      }
+    }
+    write_x();
+    lds_barrier();
+
+    for (int ts = 0; ts < t; ++ts) {
+      if (ts + 1 < t) fetch_x(ts + 1);               // in flight under this step
+      const bool recur = ts > 0 || h_init != nullptr;  // zero initial state: the h half contributes nothing
+      const char* const Hcur = Hp + (ts & 1) * 3 * PLANE;
+      char* const Hnxt = Hp + ((ts & 1) ^ 1) * 3 * PLANE;
+      // lane-derived LDS offsets recomputed per step (left loop-invariant the compiler hoists and spills them)
+      int m_ = m, q_ = q;
+      asm volatile("" : "+v"(m_), "+v"(q_));
+
+#pragma unroll
+      for (int bt = 0; bt < kBT; ++bt) {
+        const int row = bt * 16 + m_;
+        const int sw = swz<D>(row);
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          if (ks >= KSH && !recur) break;            // wave-uniform
+          const char* img = ks < KSH ? Xp : Hcur;
+          const int off = row * (D * 2) + ((((ks % KSH) * 4 + q_) ^ sw) << 4);
+          const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(img + off));
+          const bf16x8 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(img + PLANE + off));
+          const bf16x8 b3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(img + 2 * PLANE + off));
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, wf[g][ks][0]);
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, wf[g][ks][1]);
+            const bf16x8 a3 = __builtin_bit_cast(bf16x8, wf[g][ks][2]);
+            f32x4 v = acc[g];
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, v, 0, 0, 0);   // smallest terms first
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, v, 0, 0, 0);
+            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, v, 0, 0, 0);
+            acc[g] = v;
+          }
+        }
+        // ---- gate math: acc[g][r] = pre-activation of gate g, hidden hid0 + r, row `row`
+        float4 dv = make_float4(1.f, 1.f, 1.f, 1.f);
+        const int e_td = (row * t + ts) * D + hid0;    // element (row, ts, hid0) of an [n, t, D] tensor
+        if (drop) dv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, e_td * 4, 0, 0));
+        f32x4 gi, gj, gf, go, cn, hn;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gi[r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc[0][r], -kL2E, bc[0][r])));
+          gj[r] = fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc[1][r], 2.f * kL2E, bc[1][r]))), 1.f);
+          gf[r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc[2][r], -kL2E, bc[2][r])));
+          go[r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc[3][r], -kL2E, bc[3][r])));
+          cn[r] = fmaf(c[bt][r], gf[r], gi[r] * gj[r]);
+          hn[r] = fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(cn[r] * (2.f * kL2E))), 1.f) * go[r];
+        }
+        c[bt] = cn;
+        if (ts + 1 < t) write_pieces(Hnxt, row, hid0, make_float4(hn[0], hn[1], hn[2], hn[3]));
+        if (SAVE) {
+          const int go_ = (row * t + ts) * NC + hid0;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, gi), rs_g, go_ * 4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, gj), rs_g, (go_ + D) * 4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, gf), rs_g, (go_ + 2 * D) * 4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, go), rs_g, (go_ + 3 * D) * 4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, cn), rs_c, e_td * 4, 0, 0);
+        }
+        const f32x4 hv = hn * f32x4{dv.x, dv.y, dv.z, dv.w};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, hv), rs_h, (row * (int)ld_h + ts * D + hid0) * 4, 0, 0);
+      }
+      if (ts + 1 < t) {
+        lds_barrier();        // every wave has read x_ts (and h of this step) out of LDS
+        write_x();            // x_{ts+1}: its loads were issued at the top of the step
+        lds_barrier();        // x_{ts+1} and every wave's columns of h_{ts+1} are in place
+      }
+    }
+    if (c_final) {
+#pragma unroll
+      for (int bt = 0; bt < kBT; ++bt)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, c[bt]), rs_cf, ((bt * 16 + m) * D + hid0) * 4, 0, 0);
+    }
+    lds_barrier();            // the next tile's fills overwrite what slower waves may still read
+  }
+}
+
+}  // namespace
+
+namespace sagnn {
+
+bool lstm_split_supported(int d) { return d == 32 || d == 64; }
+
+template <int D, bool SAVE>
+static int launch_lstm_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, const float* W,
+                             const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
+                             float* gates_out, float* c_out, const float* h_init, int64_t ld_hi, const float* c_init,
+                             float* c_final, hipStream_t s) {
+  const size_t lds = (size_t)9 * kRows * D * 2;   // x: 3 images, h: 2 x 3 images (144 KB at D = 64)
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_fwd_split_kernel<D, SAVE>), lds)) return rc;
+  const int per_cu = D == 64 ? 1 : 2;             // D = 32: 72 KB and 2 waves per workgroup
+  const int64_t n_tiles = (n + kRows - 1) / kRows;
+  const int64_t want = (int64_t)cu_count_current() * per_cu;
+  const int64_t blocks = n_tiles < want ? n_tiles : want;
+  ProfileScope prof(kProfLstm, s, n, t);
+  hipLaunchKernelGGL((lstm_fwd_split_kernel<D, SAVE>), dim3((unsigned)blocks), dim3(64 * (D / 16)), lds, s, x, ld_n, ld_t,
+                     n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, n_tiles, h_init, ld_hi, c_init, c_final);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+int lstm_fwd_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
+                   const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h, float* gates_out,
+                   float* c_out, const float* h_init, int64_t ld_hi, const float* c_init, float* c_final,
+                   hipStream_t s) {
+  const bool save = gates_out != nullptr;
+  // 128-row tiles are addressed with 32-bit byte offsets from a per-tile base
+  if (ld_h >= (1 << 22) || (int64_t)t * d >= (1 << 18))
+    return fail(SAGNN_ERR_ARG, "split LSTM: output row stride must stay below 2^22 floats and t*d below 2^18");
+  if (ld_h < (int64_t)t * d) return fail(SAGNN_ERR_ARG, "split LSTM: ld_h = %lld < t*d", (long long)ld_h);
+#define SAGNN_LSTM_GO(DD, SV) \
+  return launch_lstm_split<DD, SV>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, h_init, ld_hi, c_init, c_final, s)
+  if (d == 64 && save) SAGNN_LSTM_GO(64, true);
+  if (d == 64) SAGNN_LSTM_GO(64, false);
+  if (d == 32 && save) SAGNN_LSTM_GO(32, true);
+  if (d == 32) SAGNN_LSTM_GO(32, false);
+#undef SAGNN_LSTM_GO
+  return fail(SAGNN_ERR_DIM, "split LSTM supports d = 32 or 64, got %d", d);
+}
+
+}  // namespace sagnn

@@ -147,8 +147,11 @@ class SplitIntervalRunner:
     per node type) because the next layer gathers from every row of the partner table."""
 
     def __init__(self, sh: SplitIntervalSharding, n_users: int, n_items: int, d: int, device, group=None,
-                 dtype=torch.float32):
+                 dtype=torch.float32, comm_device=None):
         self.sh, self.U, self.I, self.d, self.group = sh, int(n_users), int(n_items), int(d), group
+        # comm_device != device: collectives run on host copies (the gloo rehearsal on one GPU)
+        self.comm_device = torch.device(device) if comm_device is None else torch.device(comm_device)
+        self.staged = self.comm_device != torch.device(device)
         self.g = sh.group_size[sh.interval]
         self.qu, self.qi = sh.slice_rows(n_users), sh.slice_rows(n_items)
         self.ru, self.ri = sh.slice_range(n_users), sh.slice_range(n_items)
@@ -176,7 +179,12 @@ class SplitIntervalRunner:
                 break
             if self.g > 1:                                     # e^{l+1} of every member, in slice order
                 for buf, q in ((nu, self.qu), (ni, self.qi)):
-                    dist.all_gather_into_tensor(buf, buf[m * q:(m + 1) * q].clone(), group=self.group)
+                    if self.staged:
+                        full = torch.empty(buf.shape, dtype=buf.dtype, device=self.comm_device)
+                        dist.all_gather_into_tensor(full, buf[m * q:(m + 1) * q].to(self.comm_device), group=self.group)
+                        buf.copy_(full)
+                    else:
+                        dist.all_gather_into_tensor(buf, buf[m * q:(m + 1) * q].clone(), group=self.group)
             cur_u, cur_i = nu[: self.U], ni[: self.I]           # g*q >= n_rows and slices are contiguous
         return self.acc_u, self.acc_i
 
@@ -284,6 +292,14 @@ class RowShardExchange:
         cnt = min(sh.world, sh.T - j * sh.world)
         return self.x[j * sh.world: j * sh.world + cnt]
 
+    def slab(self, j: int) -> torch.Tensor:
+        """Round j's slab of x as it stands, without posting or waiting (timing passes on data already received)."""
+        sh = self.sh
+        if self._split is not None:
+            return self.x
+        cnt = min(sh.world, sh.T - j * sh.world)
+        return self.x[j * sh.world: j * sh.world + cnt]
+
     def finish(self) -> torch.Tensor:
         while self._posted < self.sh.rounds:       # rounds this rank never had an interval for
             self.post(None)
@@ -309,11 +325,11 @@ class RoundFusion:
         self.h = torch.empty((rows, sh.T, d), dtype=torch.float32, device=device)
         self.c = torch.empty((rows, d), dtype=torch.float32, device=device)
 
-    def lstm_round(self, j: int, lo: int = 0, hi: int | None = None):
+    def lstm_round(self, j: int, lo: int = 0, hi: int | None = None, wait: bool = True):
         from . import ops
         sh = self.ex.sh
         hi = self.ex.rows_local if hi is None else hi
-        xs = self.ex.wait_round(j).to(self.device)[:, lo:hi, :]              # [cnt, rows, d]
+        xs = (self.ex.wait_round(j) if wait else self.ex.slab(j)).to(self.device)[:, lo:hi, :]   # [cnt, rows, d]
         t0, cnt = j * sh.world, xs.shape[0]
         if hi <= lo or cnt == 0:
             return

@@ -178,6 +178,13 @@ def test_checkpoint_round_trip_resumes_identically(dev, tmp_path):
     # a step from reset moments or a restarted staircase would differ by ~lr = 4e-3
     assert loss_b == pytest.approx(loss_a, rel=1e-5)
     for k, v in NNs.params.items():
+        head_qk = k.startswith("mhsa") and int(k[4:k.index("_")]) >= 3 and k.split("_")[1] in ("q", "k")
+        if k.endswith("k_bias") or head_qk:
+            # gradients that are analytically ~0: a key bias shifts every score of a row alike, and the
+            # head's attention runs on a length-1 sequence (attn = e / (e + 1e-8) ~ 1 whatever Q and K are).
+            # What is left is last-bit summation noise, which Adam's m / sqrt(v) normalises to +-lr:
+            # not reproducible between two runs of the same step
+            continue
         torch.testing.assert_close(v.detach(), after_a[k], rtol=1e-4, atol=2e-5, msg=k)
     # a checkpoint that does not fit the model is refused
     args.latdim = 32
