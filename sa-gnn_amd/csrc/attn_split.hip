@@ -1,0 +1,344 @@
+// layer_norm over (T, d) -> Q/K/V dense -> exp attention -> mean over queries, one pass over h
+// (reference model.py:152-155, Utils/attention.py:35-45, 55-78), with the three dense products on
+// the bf16 matrix cores over exactly split fp32 operands (see lstm_split.hip for the arithmetic:
+// x = x1 + x2 + x3 in bf16 pieces, six piece products, fp32 accumulation; not the reduced-precision
+// bf16 GEMM — the result is as close to the float64 product as an fp32 fmaf chain is).
+//
+// A workgroup of NW = d/16 waves owns 128 GEMM rows = NB = 128/T nodes (row = nb*T + ts).
+//   fill + layer norm: 16 threads per row (float4 each). Moments per row around the row's own mean
+//     (two passes in registers), combined over the T rows of a node with the exact pairwise
+//     formula (M2 = sum M2_r + d sum (mean_r - mean)^2): two workgroup barriers, no cancellation.
+//     The normalised rows go to LDS as three bf16 images [128][d] (B fragments).
+//   Q|K|V: transposed product (W^T y^T). Wave w owns output columns 16w..16w+15 of EACH of Q, K, V
+//     — with 16 heads these are whole heads — and keeps that slice of Wq/Wk/Wv in registers as A
+//     fragments. In the 16x16 C tile a lane holds 4 consecutive columns of one row: d_k = 4 -> the
+//     q, k and v vectors of ONE head; they go to a wave-private LDS table [4][128 rows][q|k|v].
+//   attention: one lane (two for T = 16) owns one (node, head) pair outright: its T q/k/v vectors
+//     are T contiguous 48-byte records, the T x T scores, normalisers and the context run with no
+//     cross-lane traffic, and the d_k outputs leave as one vector store.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kRows = 128;
+constexpr int kBT = 8;
+constexpr int kRec = 48;   // bytes of one (row, 4-column group) record: q[4] | k[4] | v[4]
+
+struct Pieces {
+  float p1, p2, p3;
+};
+__device__ __forceinline__ Pieces split3(float x) {
+  Pieces s;
+  s.p1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u);
+  const float r = x - s.p1;
+  s.p2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r) & 0xFFFF0000u);
+  s.p3 = r - s.p2;
+  return s;
+}
+__device__ __forceinline__ int pack_hi(float lo, float hi) {
+  return (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
+}
+template <int D>
+__device__ __forceinline__ int swz(int row) {
+  if (D == 64) return (row >> 1) & 7;
+  const int g = (row >> 2) & 3;
+  return (0x78 >> (2 * g)) & 3;
+}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Padding of a wave's q|k|v table, found by enumerating the bank sets of the attention phase's vector
+// reads (one lane per (node, head) pair; ds_read_b128 lane groups {0-3, 12-15, 20-27}, ...): without
+// it the 6144-byte head-group stride and the T*48-byte node stride are multiples of 256 bytes for
+// T = 8, 16 and every pair of a lane group lands on the same banks (8-way; 4-way for the other T).
+// kPadNode bytes after each node's T records, kPadGroup bytes after each 4-column group.
+// Conflict-free for every T below except T = 2 (2-way; a per-node pad would not fit LDS at d = 64).
+__host__ __device__ constexpr int pad_node(int t) { return (t == 6 || t == 8 || t == 16) ? 16 : 0; }
+__host__ __device__ constexpr int pad_group(int t, int dk) {
+  return (t == 1 || t == 3 || t == 5 || t == 8) ? 64 : t == 6 ? 112 : (t == 16 && dk == 4) ? 0 : 16;
+}
+
+// T: intervals (compile time). QSPLIT: lanes per (node, head) pair (2 splits the queries in halves).
+template <int D, int T, int QSPLIT>
+__global__ __launch_bounds__(64 * (D / 16), 1) void ln_mhsa_split_kernel(
+    const float* __restrict__ x, int64_t ld_n, int64_t ld_t, int64_t n, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float eps, int apply_ln, const float* __restrict__ Wq,
+    const float* __restrict__ bq, const float* __restrict__ Wk, const float* __restrict__ bk,
+    const float* __restrict__ Wv, const float* __restrict__ bv, float* __restrict__ out, int64_t ld_out,
+    int64_t n_tiles) {
+  constexpr int NW = D / 16, NT = 64 * NW, KS = D / 32;
+  constexpr int DK = D / 16;                    // 16 heads
+  constexpr int HPW = 16 / DK;                  // heads per wave
+  constexpr int NB = kRows / T;                 // nodes per tile
+  constexpr int ROWS = NB * T;                  // rows in use
+  constexpr int PLANE = kRows * D * 2;
+  constexpr int LPR = D / 4, RPP = NT / LPR, NFILL = kRows / RPP;
+  constexpr int PN = pad_node(T), PG = pad_group(T, D / 16);
+  constexpr int GS = kRows * kRec + NB * PN + PG;   // bytes of one 4-column group of the table
+  constexpr int QKVW = 4 * GS;                  // bytes of one wave's q|k|v table
+  typedef float vec __attribute__((ext_vector_type(DK)));
+
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  char* const Yp = lds;                                     // 3 images
+  char* const QKV = lds + 3 * PLANE;                        // NW tables
+  float2* const rstat = reinterpret_cast<float2*>(QKV + NW * QKVW);   // [128] (mean_r, M2_r)
+  float2* const nstat = rstat + kRows;                      // [NB] (mean, rstd)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, q = lane >> 4;
+  const int col0 = 16 * wave + 4 * q;           // this lane's 4 output columns of each of Q, K, V
+  const int fr = tid / LPR, fc4 = (tid % LPR) * 4;
+  char* const tab = QKV + wave * QKVW;
+
+  // ---- this wave's slices of Wq / Wk / Wv as A fragments: A[mm][k = 32 ks + 8 q + j] = W[k][16 wave + mm]
+  i32x4 wf[3][KS][3];
+  {
+    const float* const Ws[3] = {Wq, Wk, Wv};
+#pragma unroll
+    for (int mat = 0; mat < 3; ++mat)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        Pieces pc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pc[j] = split3(Ws[mat][(size_t)(32 * ks + 8 * q + j) * D + 16 * wave + m]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          wf[mat][ks][0][e] = pack_hi(pc[2 * e].p1, pc[2 * e + 1].p1);
+          wf[mat][ks][1][e] = pack_hi(pc[2 * e].p2, pc[2 * e + 1].p2);
+          wf[mat][ks][2][e] = pack_hi(pc[2 * e].p3, pc[2 * e + 1].p3);
+        }
+      }
+  }
+  f32x4 bias3[3];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    bias3[0][r] = bq[col0 + r];
+    bias3[1][r] = bk[col0 + r];
+    bias3[2][r] = bv[col0 + r];
+  }
+  float4 g4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (apply_ln) {
+    g4 = *reinterpret_cast<const float4*>(gamma + fc4);
+    b4 = *reinterpret_cast<const float4*>(beta + fc4);
+  }
+  const float scale = DK == 4 ? 0.5f : 0.70710678118654752440f;   // 1 / sqrt(d_k)
+  const float inv_t = 1.f / (float)T;
+
+  float4 xr[NFILL];
+  auto fetch_tile = [&](int64_t tile) {
+    const int64_t node0 = tile * NB;
+#pragma unroll
+    for (int p = 0; p < NFILL; ++p) {
+      const int r = p * RPP + fr;
+      const int nb = r / T, ts = r - nb * T;
+      xr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tile < n_tiles && r < ROWS && node0 + nb < n)
+        xr[p] = *reinterpret_cast<const float4*>(x + (node0 + nb) * ld_n + (int64_t)ts * ld_t + fc4);
+    }
+  };
+  fetch_tile(blockIdx.x);
+
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t node0 = tile * NB;
+    int fr_ = fr, fc4_ = fc4, m_ = m, q_ = q;
+    asm volatile("" : "+v"(fr_), "+v"(fc4_), "+v"(m_), "+v"(q_));
+
+    // ---- layer norm moments: per row around the row mean, then the exact combination over a node's rows
+    if (apply_ln) {
+#pragma unroll
+      for (int p = 0; p < NFILL; ++p) {
+        float s = (xr[p].x + xr[p].y) + (xr[p].z + xr[p].w);
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
+        const float mr = s * (1.f / (float)D);
+        const float dx = xr[p].x - mr, dy = xr[p].y - mr, dz = xr[p].z - mr, dw = xr[p].w - mr;
+        float m2 = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) m2 += __shfl_xor(m2, o);
+        if (fc4_ == 0) rstat[p * RPP + fr_] = make_float2(mr, m2);
+      }
+      lds_barrier();
+      if (tid < NB) {
+        float ms = 0.f;
+#pragma unroll
+        for (int ts = 0; ts < T; ++ts) ms += rstat[tid * T + ts].x;
+        const float mean = ms * inv_t;
+        float m2 = 0.f;
+#pragma unroll
+        for (int ts = 0; ts < T; ++ts) {
+          const float2 st = rstat[tid * T + ts];
+          const float dm = st.x - mean;
+          m2 += st.y + (float)D * dm * dm;
+        }
+        nstat[tid] = make_float2(mean, rsqrtf(m2 * (1.f / (float)(T * D)) + eps));
+      }
+      lds_barrier();
+    }
+    // ---- normalise, split into bf16 pieces, store the three images
+#pragma unroll
+    for (int p = 0; p < NFILL; ++p) {
+      const int r = p * RPP + fr_;
+      float4 y = xr[p];
+      if (apply_ln) {
+        const float2 st = nstat[r < ROWS ? r / T : 0];
+        const float ix = st.y * g4.x, iy = st.y * g4.y, iz = st.y * g4.z, iw = st.y * g4.w;
+        y.x = xr[p].x * ix + (b4.x - st.x * ix);
+        y.y = xr[p].y * iy + (b4.y - st.x * iy);
+        y.z = xr[p].z * iz + (b4.z - st.x * iz);
+        y.w = xr[p].w * iw + (b4.w - st.x * iw);
+      }
+      const Pieces a = split3(y.x), b = split3(y.y), c = split3(y.z), d = split3(y.w);
+      const int off = r * (D * 2) + (((fc4_ >> 3) ^ swz<D>(r)) << 4) + ((fc4_ >> 2) & 1) * 8;
+      *reinterpret_cast<i32x2*>(Yp + off) = i32x2{pack_hi(a.p1, b.p1), pack_hi(c.p1, d.p1)};
+      *reinterpret_cast<i32x2*>(Yp + PLANE + off) = i32x2{pack_hi(a.p2, b.p2), pack_hi(c.p2, d.p2)};
+      *reinterpret_cast<i32x2*>(Yp + 2 * PLANE + off) = i32x2{pack_hi(a.p3, b.p3), pack_hi(c.p3, d.p3)};
+    }
+    fetch_tile(tile + gridDim.x);   // next tile's rows, in flight under this tile's products and attention
+    lds_barrier();
+
+    // ---- Q | K | V columns of this wave for every row of the tile -> the wave's table
+#pragma unroll
+    for (int bt = 0; bt < kBT; ++bt) {
+      const int row = bt * 16 + m_;
+      const int sw = swz<D>(row);
+      f32x4 acc[3] = {bias3[0], bias3[1], bias3[2]};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = row * (D * 2) + (((ks * 4 + q_) ^ sw) << 4);
+        const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(Yp + off));
+        const bf16x8 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(Yp + PLANE + off));
+        const bf16x8 b3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(Yp + 2 * PLANE + off));
+#pragma unroll
+        for (int mat = 0; mat < 3; ++mat) {
+          const bf16x8 a1 = __builtin_bit_cast(bf16x8, wf[mat][ks][0]);
+          const bf16x8 a2 = __builtin_bit_cast(bf16x8, wf[mat][ks][1]);
+          const bf16x8 a3 = __builtin_bit_cast(bf16x8, wf[mat][ks][2]);
+          f32x4 v = acc[mat];
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, v, 0, 0, 0);
+          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, v, 0, 0, 0);
+          acc[mat] = v;
+        }
+      }
+      char* rec = tab + q_ * GS + row * kRec + (row / T) * PN;
+      *reinterpret_cast<f32x4*>(rec) = acc[0];
+      *reinterpret_cast<f32x4*>(rec + 16) = acc[1];
+      *reinterpret_cast<f32x4*>(rec + 32) = acc[2];
+    }
+    lds_barrier();   // table complete (wave-private), and every wave is done reading the y images
+
+    // ---- attention of each (node, head) pair of this wave's heads
+    constexpr int PAIRS = NB * HPW;
+    constexpr int LSTEP = 64 / QSPLIT;
+    constexpr int TQ = T / QSPLIT;            // queries per lane
+    for (int p = lane / QSPLIT; p < PAIRS; p += LSTEP) {
+      const int hl = p % HPW, nb = p / HPW;
+      const int half = lane % QSPLIT;
+      const char* base = tab + ((hl * DK) >> 2) * GS + nb * (T * kRec + PN) + ((hl * DK) & 3) * 4;
+      vec k[T], v[T];
+#pragma unroll
+      for (int s = 0; s < T; ++s) {
+        k[s] = *reinterpret_cast<const vec*>(base + s * kRec + 16);
+        v[s] = *reinterpret_cast<const vec*>(base + s * kRec + 32);
+      }
+      vec o = (vec)(0.f);
+#pragma unroll
+      for (int i = 0; i < TQ; ++i) {
+        const int tq = half * TQ + i;
+        const vec qv = *reinterpret_cast<const vec*>(base + tq * kRec) * scale;
+        vec ctx = (vec)(0.f);
+        float rs = 0.f;
+#pragma unroll
+        for (int s = 0; s < T; ++s) {
+          float pd = qv[0] * k[s][0];
+#pragma unroll
+          for (int c = 1; c < DK; ++c) pd = fmaf(qv[c], k[s][c], pd);
+          const float e = __expf(pd);
+          rs += e;
+          ctx += e * v[s];
+        }
+        o += ctx * __builtin_amdgcn_rcpf(rs + 1e-8f);
+      }
+      if (QSPLIT == 2) {
+        // The other half's queries sit in lane ^ 1. The partial sums meet through the wave's own table:
+        // the odd lane parks its o in the q slot of the pair's first record (every q of the pair has been
+        // read by now: LDS operations of a wave complete in issue order) and the even lane adds it to its
+        // own. Cross-lane forms measured WRONG here on ROCm 7.2 / gfx950: the update_dpp
+        // loop was miscompiled (two DPP instructions for four components) and __shfl_xor (ds_bpermute)
+        // returned stale values in ~1e-4 of the pairs with two workgroups per CU.
+        char* slot = const_cast<char*>(base);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (half == 1) *reinterpret_cast<vec*>(slot) = o;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        o += *reinterpret_cast<const vec*>(slot);   // meaningful on the even lane, which stores
+      }
+      const int64_t node = node0 + nb;
+      if (half == 0 && node < n) *reinterpret_cast<vec*>(out + node * ld_out + 16 * wave + hl * DK) = o * inv_t;
+    }
+    // the next tile's products overwrite the table only after its own barriers; its fill overwrites
+    // the y images, which every wave finished reading before the barrier above
+  }
+}
+
+}  // namespace
+
+namespace sagnn {
+
+bool mhsa_split_supported(int d, int t, int heads) {
+  if (heads != 16 || !(d == 32 || d == 64)) return false;
+  return (t >= 1 && t <= 6) || t == 8 || t == 12 || t == 16;
+}
+
+template <int D, int T, int QSPLIT>
+static int launch_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, const float* gamma, const float* beta,
+                        float eps, int apply_ln, const float* Wq, const float* bq, const float* Wk, const float* bk,
+                        const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s) {
+  constexpr int NW = D / 16, NB = kRows / T;
+  constexpr int GS = kRows * kRec + NB * pad_node(T) + pad_group(T, D / 16);
+  const size_t lds = (size_t)3 * kRows * D * 2 + (size_t)NW * 4 * GS + (size_t)(kRows + NB) * sizeof(float2);
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&ln_mhsa_split_kernel<D, T, QSPLIT>), lds)) return rc;
+  const int per_cu = D == 64 ? 1 : 2;
+  const int64_t n_tiles = (n + NB - 1) / NB;
+  const int64_t want = (int64_t)cu_count_current() * per_cu;
+  const int64_t blocks = n_tiles < want ? n_tiles : want;
+  ProfileScope prof(kProfMhsa, s, n, T);
+  hipLaunchKernelGGL((ln_mhsa_split_kernel<D, T, QSPLIT>), dim3((unsigned)blocks), dim3(64 * NW), lds, s, x, ld_n, ld_t, n,
+                     gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, n_tiles);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+template <int D>
+static int dispatch_t(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, const float* gamma,
+                      const float* beta, float eps, int apply_ln, const float* Wq, const float* bq, const float* Wk,
+                      const float* bk, const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s) {
+#define SAGNN_T_CASE(TT, QS) \
+  case TT: return launch_split<D, TT, QS>(x, ld_n, ld_t, n, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
+  switch (t) {
+    SAGNN_T_CASE(1, 1) SAGNN_T_CASE(2, 1) SAGNN_T_CASE(3, 1) SAGNN_T_CASE(4, 1) SAGNN_T_CASE(5, 1) SAGNN_T_CASE(6, 1)
+    SAGNN_T_CASE(8, 1) SAGNN_T_CASE(12, 1) SAGNN_T_CASE(16, 2)
+    default: return fail(SAGNN_ERR_DIM, "split attention: t = %d has no specialised kernel", t);
+  }
+#undef SAGNN_T_CASE
+}
+
+int ln_mhsa_mean_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
+                       const float* gamma, const float* beta, float eps, int apply_ln, const float* Wq,
+                       const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
+                       float* out, int64_t ld_out, hipStream_t s) {
+  if (!mhsa_split_supported(d, t, heads)) return fail(SAGNN_ERR_DIM, "split attention: unsupported d/t/heads");
+  if (d == 64) return dispatch_t<64>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
+  return dispatch_t<32>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
+}
+
+}  // namespace sagnn

@@ -1034,6 +1034,9 @@ int ln_mhsa_mean_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int
                       const float* gamma, const float* beta, float eps, int apply_ln, const float* Wq,
                       const float* bq, const float* Wk, const float* bk, const float* Wv,
                       const float* bv, float* out, int64_t ld_out, hipStream_t s) {
+  if (mhsa_split_supported(d, t, heads) && !force_f32_mfma())
+    return ln_mhsa_mean_split(x, ld_n, ld_t, n, t, d, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out,
+                              ld_out, s);
   if (d == 64)
     return launch_ln_mhsa<64>(x, ld_n, ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
   if (d == 32)

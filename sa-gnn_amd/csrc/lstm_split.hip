@@ -15,14 +15,19 @@
 // Six bf16 MFMAs cost 6/16 of one fp32 MFMA, and VALU work issues beside bf16 MFMAs.
 //
 // Decomposition (transposed product, gates^T = W^T [x|h]^T): a workgroup of NW = d/16 waves owns
-// 128 rows; wave w owns hidden units 16w .. 16w+15 of all four gates. Its slice of W stays in
+// 96 rows; wave w owns hidden units 16w .. 16w+15 of all four gates. Its slice of W stays in
 // REGISTERS for the whole kernel as ready-made A fragments (4 gates x 2d/32 k-steps x 3 pieces).
-// x_t and h are shared through LDS as three bf16 images [128][d] each (B fragments: one
+// x_t and h are shared through LDS as three bf16 images [96][d] each (B fragments: one
 // ds_read_b128 per lane, 16-byte slots XOR-swizzled with the row so reads and writes are
 // conflict-free). In the 16x16 C tile a lane holds 4 consecutive hidden units of ONE row, for all
 // four gates: the gate math needs no cross-lane traffic, h leaves as 16-byte stores, and its three
-// pieces go back to LDS as 8-byte writes. h is double-buffered in LDS, x single (its next step is
-// prefetched into registers): two workgroup barriers per step.
+// pieces go back to LDS as 8-byte writes. x and h are both double-buffered in LDS (12 images =
+// 144 KB at d = 64; the next step's x is prefetched into registers and written at the end of the
+// step): ONE workgroup barrier per step. The gate math of a batch tile is hand-interleaved with the
+// MFMAs of the next one (see `step`).
+#include <type_traits>
+#include <utility>
+
 #include "common.h"
 
 namespace {
@@ -32,8 +37,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kRows = 128;  // rows per workgroup tile
-constexpr int kBT = 8;      // batch tiles of 16 rows
+constexpr int kBT = 6;             // batch tiles of 16 rows per workgroup tile
+constexpr int kRows = 16 * kBT;    // 96 rows: x and h both double-buffered in LDS = 12 images = 144 KB at d = 64
 
 // x = p1 + p2 + p3 exactly, each piece a bf16 value held in the top 16 bits of a float.
 struct Pieces {
@@ -63,6 +68,16 @@ __device__ __forceinline__ int swz(int row) {
   return (0x78 >> (2 * g)) & 3;       // 0b01'11'10'00 read from the low end: g=0 -> 0, 1 -> 2, 2 -> 3, 3 -> 1
 }
 
+// f(integral_constant<int, LO>), ..., f(integral_constant<int, HI-1>) in order
+template <int LO, class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, LO + I>{}), ...);
+}
+template <int LO, int HI, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (HI > LO) static_for_impl<LO>(static_cast<F&&>(f), std::make_integer_sequence<int, HI - LO>{});
+}
+
 __device__ __forceinline__ void lds_barrier() {
   // LDS traffic only: outstanding global loads (the x prefetch) and stores stay in flight across it
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -82,12 +97,12 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
   constexpr int PLANE = kRows * D * 2;          // bytes of one bf16 image
   constexpr int LPR = D / 4;                    // threads per row in the fill (float4 each)
   constexpr int RPP = NT / LPR;                 // rows per fill pass (16)
-  constexpr int NFILL = kRows / RPP;            // 8
+  constexpr int NFILL = kRows / RPP;            // 6
   constexpr float kL2E = 1.44269504088896340736f;
 
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  char* const Xp = lds;                         // 3 images
-  char* const Hp = lds + 3 * PLANE;             // 2 x 3 images
+  char* const Xp = lds;                         // 2 x 3 images
+  char* const Hp = lds + 6 * PLANE;             // 2 x 3 images
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,9 +157,9 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
         if (r < rows_valid) xr[p] = *reinterpret_cast<const float4*>(x + (row0 + r) * ld_n + (int64_t)ts * ld_t + fc4);
       }
     };
-    auto write_x = [&]() {
+    auto write_x = [&](int buf) {
 #pragma unroll
-      for (int p = 0; p < NFILL; ++p) write_pieces(Xp, p * RPP + fr, fc4, xr[p]);
+      for (int p = 0; p < NFILL; ++p) write_pieces(Xp + buf * 3 * PLANE, p * RPP + fr, fc4, xr[p]);
     };
     fetch_x(0);
 
@@ -176,79 +191,171 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
         write_pieces(Hp, r, fc4, v);
       }
     }
-    write_x();
+    write_x(0);
     lds_barrier();
 
-    for (int ts = 0; ts < t; ++ts) {
-      if (ts + 1 < t) fetch_x(ts + 1);               // in flight under this step
-      const bool recur = ts > 0 || h_init != nullptr;  // zero initial state: the h half contributes nothing
+    const float no_drop = drop ? 0.f : 1.f;   // a missing mask reads 0 through the empty descriptor
+
+    // One step, hand-scheduled. The MFMAs of batch tile bt (6 piece products x 4 gates x k-steps,
+    // one accumulator chain per gate) are issued one at a time, and after each one a slice of the
+    // gate math of tile bt-1 — a fixed list of kOps single-instruction operations — is emitted,
+    // closed by a scheduling barrier so the order survives the compiler: VALU and transcendental
+    // issue slots beside a bf16 MFMA are otherwise left empty (its scheduler keeps MFMAs and the
+    // dependent-free gate math in two separate runs), and B fragments are requested one k-step
+    // ahead of the MFMAs that read them.
+    auto step = [&](auto recur_c, int ts) {
+      constexpr bool RECUR = decltype(recur_c)::value;
+      constexpr int KSN = RECUR ? KS : KSH;           // k-steps per tile
+      constexpr int NM = 24 * KSN;                    // MFMAs per tile
+      constexpr int kOps = 127;
+      const char* const Xcur = Xp + (ts & 1) * 3 * PLANE;
       const char* const Hcur = Hp + (ts & 1) * 3 * PLANE;
       char* const Hnxt = Hp + ((ts & 1) ^ 1) * 3 * PLANE;
       // lane-derived LDS offsets recomputed per step (left loop-invariant the compiler hoists and spills them)
       int m_ = m, q_ = q;
       asm volatile("" : "+v"(m_), "+v"(q_));
+      const int hid = 16 * wave + 4 * q_;
 
-#pragma unroll
-      for (int bt = 0; bt < kBT; ++bt) {
+      f32x4 acc[4];                    // tile in flight
+      f32x4 ga[4];                     // pre-activations of the tile whose gate math is being interleaved
+      f32x4 dv;                        // dropout scale of that tile
+      float tt[4][4], pr[4], cn[4], u[4], hn[4], hv[4], p1[4], r1[4], p2[4], p3[4];
+      int w0[2], w1[2], w2[2], hoff;
+      i32x4 bf[2][3];                  // B fragments, double-buffered across k-steps
+
+      auto read_b = [&](int bt, int ks, i32x4 (&dst)[3]) {
         const int row = bt * 16 + m_;
-        const int sw = swz<D>(row);
-        f32x4 acc[4];
+        const char* img = ks < KSH ? Xcur : Hcur;
+        const int off = row * (D * 2) + ((((ks % KSH) * 4 + q_) ^ swz<D>(row)) << 4);
+        dst[0] = *reinterpret_cast<const i32x4*>(img + off);
+        dst[1] = *reinterpret_cast<const i32x4*>(img + PLANE + off);
+        dst[2] = *reinterpret_cast<const i32x4*>(img + 2 * PLANE + off);
+      };
+      // operation K of the gate math of tile PB (state in ga / tt / ...): one instruction each, more or less
+      auto gate_op = [&](auto pb_c, auto k_c) {
+        constexpr int PB = decltype(pb_c)::value, K = decltype(k_c)::value;
+        constexpr int R = K & 3, G = (K >> 2) & 3;
+        const int row = PB * 16 + m_;
+        if constexpr (K == 0) {
+          const int e_td = (row * t + ts) * D + hid;
+          dv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, e_td * 4, 0, 0));
+        } else if constexpr (K < 17) {          // 1..16: scaled pre-activation + bias
+          constexpr int k = K - 1, g = k >> 2, r = k & 3;
+          tt[g][r] = fmaf(ga[g][r], g == 1 ? 2.f * kL2E : -kL2E, bc[g][r]);
+        } else if constexpr (K < 33) {
+          constexpr int k = K - 17, g = k >> 2, r = k & 3;
+          tt[g][r] = __builtin_amdgcn_exp2f(tt[g][r]);
+        } else if constexpr (K < 49) {
+          constexpr int k = K - 33, g = k >> 2, r = k & 3;
+          tt[g][r] = 1.f + tt[g][r];
+        } else if constexpr (K < 65) {
+          constexpr int k = K - 49, g = k >> 2, r = k & 3;
+          tt[g][r] = __builtin_amdgcn_rcpf(tt[g][r]);       // sigmoid(i), 1/(1+e^2j), sigmoid(f), sigmoid(o)
+        } else if constexpr (K < 69) {
+          tt[1][K - 65] = fmaf(-2.f, tt[1][K - 65], 1.f);     // tanh(j)
+        } else if constexpr (K < 73) {
+          pr[K - 69] = tt[0][K - 69] * tt[1][K - 69];
+        } else if constexpr (K < 77) {
+          cn[K - 73] = fmaf(c[PB][K - 73], tt[2][K - 73], pr[K - 73]);
+        } else if constexpr (K < 81) {
+          u[K - 77] = cn[K - 77] * (2.f * kL2E);
+        } else if constexpr (K < 85) {
+          u[K - 81] = __builtin_amdgcn_exp2f(u[K - 81]);
+        } else if constexpr (K < 89) {
+          u[K - 85] = 1.f + u[K - 85];
+        } else if constexpr (K < 93) {
+          u[K - 89] = __builtin_amdgcn_rcpf(u[K - 89]);
+        } else if constexpr (K < 97) {
+          u[K - 93] = fmaf(-2.f, u[K - 93], 1.f);             // tanh(c')
+        } else if constexpr (K < 101) {
+          hn[K - 97] = u[K - 97] * tt[3][K - 97];
+        } else if constexpr (K < 105) {
+          hv[K - 101] = hn[K - 101] * (dv[K - 101] + no_drop);
+        } else if constexpr (K < 109) {
+          p1[K - 105] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, hn[K - 105]) & 0xFFFF0000u);
+        } else if constexpr (K < 113) {
+          r1[K - 109] = hn[K - 109] - p1[K - 109];
+        } else if constexpr (K < 117) {
+          p2[K - 113] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1[K - 113]) & 0xFFFF0000u);
+        } else if constexpr (K < 121) {
+          p3[K - 117] = r1[K - 117] - p2[K - 117];
+        } else if constexpr (K == 121) {
+          w0[0] = pack_hi(p1[0], p1[1]);
+          w0[1] = pack_hi(p1[2], p1[3]);
+        } else if constexpr (K == 122) {
+          w1[0] = pack_hi(p2[0], p2[1]);
+          w1[1] = pack_hi(p2[2], p2[3]);
+        } else if constexpr (K == 123) {
+          w2[0] = pack_hi(p3[0], p3[1]);
+          w2[1] = pack_hi(p3[2], p3[3]);
+          hoff = row * (D * 2) + (((hid >> 3) ^ swz<D>(row)) << 4) + ((hid >> 2) & 1) * 8;
+        } else if constexpr (K == 124) {
+          // always written: after the last step nothing reads it (no branch in the interleaved stream)
+          *reinterpret_cast<i32x2*>(Hnxt + hoff) = i32x2{w0[0], w0[1]};
+          *reinterpret_cast<i32x2*>(Hnxt + PLANE + hoff) = i32x2{w1[0], w1[1]};
+          *reinterpret_cast<i32x2*>(Hnxt + 2 * PLANE + hoff) = i32x2{w2[0], w2[1]};
+        } else if constexpr (K == 125) {
+          const i32x4 hvv = {__builtin_bit_cast(int, hv[0]), __builtin_bit_cast(int, hv[1]), __builtin_bit_cast(int, hv[2]),
+                             __builtin_bit_cast(int, hv[3])};
+          __builtin_amdgcn_raw_buffer_store_b128(hvv, rs_h, (row * (int)ld_h + ts * D + hid) * 4, 0, 0);
+          c[PB] = f32x4{cn[0], cn[1], cn[2], cn[3]};
+        } else if constexpr (K == 126) {
+          if (SAVE) {
+            const int e_td = (row * t + ts) * D + hid;
+            const int go_ = (row * t + ts) * NC + hid;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          if (ks >= KSH && !recur) break;            // wave-uniform
-          const char* img = ks < KSH ? Xp : Hcur;
-          const int off = row * (D * 2) + ((((ks % KSH) * 4 + q_) ^ sw) << 4);
-          const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(img + off));
-          const bf16x8 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(img + PLANE + off));
-          const bf16x8 b3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(img + 2 * PLANE + off));
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const bf16x8 a1 = __builtin_bit_cast(bf16x8, wf[g][ks][0]);
-            const bf16x8 a2 = __builtin_bit_cast(bf16x8, wf[g][ks][1]);
-            const bf16x8 a3 = __builtin_bit_cast(bf16x8, wf[g][ks][2]);
-            f32x4 v = acc[g];
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, v, 0, 0, 0);   // smallest terms first
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, v, 0, 0, 0);
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, v, 0, 0, 0);
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, v, 0, 0, 0);
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, v, 0, 0, 0);
-            v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, v, 0, 0, 0);
-            acc[g] = v;
+            for (int g = 0; g < 4; ++g) {
+              const i32x4 gv = {__builtin_bit_cast(int, tt[g][0]), __builtin_bit_cast(int, tt[g][1]),
+                                __builtin_bit_cast(int, tt[g][2]), __builtin_bit_cast(int, tt[g][3])};
+              __builtin_amdgcn_raw_buffer_store_b128(gv, rs_g, (go_ + g * D) * 4, 0, 0);
+            }
+            const i32x4 cv = {__builtin_bit_cast(int, cn[0]), __builtin_bit_cast(int, cn[1]), __builtin_bit_cast(int, cn[2]),
+                              __builtin_bit_cast(int, cn[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(cv, rs_c, e_td * 4, 0, 0);
           }
         }
-        // ---- gate math: acc[g][r] = pre-activation of gate g, hidden hid0 + r, row `row`
-        float4 dv = make_float4(1.f, 1.f, 1.f, 1.f);
-        const int e_td = (row * t + ts) * D + hid0;    // element (row, ts, hid0) of an [n, t, D] tensor
-        if (drop) dv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, e_td * 4, 0, 0));
-        f32x4 gi, gj, gf, go, cn, hn;
+        (void)R;
+        (void)G;
+      };
+      // MFMA number I of tile BT, then the slice [I kOps / NM, (I+1) kOps / NM) of tile BT-1's gate math
+      auto slot = [&](auto bt_c, auto i_c) {
+        constexpr int BT = decltype(bt_c)::value, I = decltype(i_c)::value;
+        constexpr int ks = I / 24, g = (I % 24) / 6, term = I % 6;
+        constexpr int cur = (BT * KSN + ks) & 1;
+        if constexpr (I % 24 == 0) {               // request the next k-step's (or the next tile's first) fragments
+          if constexpr (ks + 1 < KSN) read_b(BT, ks + 1, bf[cur ^ 1]);
+          else if constexpr (BT + 1 < kBT) read_b(BT + 1, 0, bf[cur ^ 1]);
+        }
+        // piece products, smallest first: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1
+        constexpr int ai = term == 0 ? 2 : (term == 2 || term == 3) ? 1 : 0;
+        constexpr int bi = term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
+        const f32x4 cin = (ks == 0 && term == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[g];
+        acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[g][ks][ai]),
+                                                         __builtin_bit_cast(bf16x8, bf[cur][bi]), cin, 0, 0, 0);
+        if constexpr (BT > 0) {
+          constexpr int lo = I * kOps / NM, hi = (I + 1) * kOps / NM;
+          static_for<lo, hi>([&](auto k_c) { gate_op(std::integral_constant<int, BT - 1>{}, k_c); });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto tile = [&](auto bt_c) {
+        constexpr int BT = decltype(bt_c)::value;
+        static_for<0, NM>([&](auto i_c) { slot(bt_c, i_c); });
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          gi[r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc[0][r], -kL2E, bc[0][r])));
-          gj[r] = fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc[1][r], 2.f * kL2E, bc[1][r]))), 1.f);
-          gf[r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc[2][r], -kL2E, bc[2][r])));
-          go[r] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(fmaf(acc[3][r], -kL2E, bc[3][r])));
-          cn[r] = fmaf(c[bt][r], gf[r], gi[r] * gj[r]);
-          hn[r] = fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(cn[r] * (2.f * kL2E))), 1.f) * go[r];
-        }
-        c[bt] = cn;
-        if (ts + 1 < t) write_pieces(Hnxt, row, hid0, make_float4(hn[0], hn[1], hn[2], hn[3]));
-        if (SAVE) {
-          const int go_ = (row * t + ts) * NC + hid0;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, gi), rs_g, go_ * 4, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, gj), rs_g, (go_ + D) * 4, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, gf), rs_g, (go_ + 2 * D) * 4, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, go), rs_g, (go_ + 3 * D) * 4, 0, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, cn), rs_c, e_td * 4, 0, 0);
-        }
-        const f32x4 hv = hn * f32x4{dv.x, dv.y, dv.z, dv.w};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, hv), rs_h, (row * (int)ld_h + ts * D + hid0) * 4, 0, 0);
-      }
+        for (int g = 0; g < 4; ++g) ga[g] = acc[g];
+      };
+      read_b(0, 0, bf[0]);
+      static_for<0, kBT>(tile);
+      static_for<0, kOps>([&](auto k_c) { gate_op(std::integral_constant<int, kBT - 1>{}, k_c); });   // the last tile's gates
+    };
+
+    for (int ts = 0; ts < t; ++ts) {
+      if (ts + 1 < t) fetch_x(ts + 1);               // in flight under this step
+      if (ts > 0 || h_init != nullptr) step(std::true_type{}, ts);
+      else step(std::false_type{}, ts);               // zero initial state: the h half contributes nothing
       if (ts + 1 < t) {
-        lds_barrier();        // every wave has read x_ts (and h of this step) out of LDS
-        write_x();            // x_{ts+1}: its loads were issued at the top of the step
-        lds_barrier();        // x_{ts+1} and every wave's columns of h_{ts+1} are in place
+        write_x((ts + 1) & 1);   // x_{ts+1} into the other buffer: its loads were issued at the top of the step
+        lds_barrier();           // x_{ts+1} and every wave's columns of h_{ts+1} are in place; x_ts / h_ts are free
       }
     }
     if (c_final) {
@@ -271,7 +378,7 @@ static int launch_lstm_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t
                              const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
                              float* gates_out, float* c_out, const float* h_init, int64_t ld_hi, const float* c_init,
                              float* c_final, hipStream_t s) {
-  const size_t lds = (size_t)9 * kRows * D * 2;   // x: 3 images, h: 2 x 3 images (144 KB at D = 64)
+  const size_t lds = (size_t)12 * kRows * D * 2;  // x and h: 2 x 3 images each (144 KB at D = 64)
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_fwd_split_kernel<D, SAVE>), lds)) return rc;
   const int per_cu = D == 64 ? 1 : 2;             // D = 32: 72 KB and 2 waves per workgroup
   const int64_t n_tiles = (n + kRows - 1) / kRows;
@@ -289,7 +396,7 @@ int lstm_fwd_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t,
                    float* c_out, const float* h_init, int64_t ld_hi, const float* c_init, float* c_final,
                    hipStream_t s) {
   const bool save = gates_out != nullptr;
-  // 128-row tiles are addressed with 32-bit byte offsets from a per-tile base
+  // the tile's rows are addressed with 32-bit byte offsets from a per-tile base
   if (ld_h >= (1 << 22) || (int64_t)t * d >= (1 << 18))
     return fail(SAGNN_ERR_ARG, "split LSTM: output row stride must stay below 2^22 floats and t*d below 2^18");
   if (ld_h < (int64_t)t * d) return fail(SAGNN_ERR_ARG, "split LSTM: ld_h = %lld < t*d", (long long)ld_h);
