@@ -4,18 +4,21 @@
 // x = x1 + x2 + x3 in bf16 pieces, six piece products, fp32 accumulation; not the reduced-precision
 // bf16 GEMM — the result is as close to the float64 product as an fp32 fmaf chain is).
 //
-// A workgroup of NW = d/16 waves owns 128 GEMM rows = NB = 128/T nodes (row = nb*T + ts).
+// A workgroup of NW = d/16 waves owns 64 GEMM rows = NB = 64/T nodes (row = nb*T + ts); it needs
+// ~76 KB of LDS and <= 256 registers, so TWO workgroups share a CU (two waves per SIMD): one's
+// attention phase (VALU + LDS latency) runs beside the other's products (matrix pipe).
 //   fill + layer norm: 16 threads per row (float4 each). Moments per row around the row's own mean
 //     (two passes in registers), combined over the T rows of a node with the exact pairwise
 //     formula (M2 = sum M2_r + d sum (mean_r - mean)^2): two workgroup barriers, no cancellation.
-//     The normalised rows go to LDS as three bf16 images [128][d] (B fragments).
+//     The normalised rows go to LDS as three bf16 images [64][d] (B fragments).
 //   Q|K|V: transposed product (W^T y^T). Wave w owns output columns 16w..16w+15 of EACH of Q, K, V
 //     — with 16 heads these are whole heads — and keeps that slice of Wq/Wk/Wv in registers as A
 //     fragments. In the 16x16 C tile a lane holds 4 consecutive columns of one row: d_k = 4 -> the
-//     q, k and v vectors of ONE head; they go to a wave-private LDS table [4][128 rows][q|k|v].
-//   attention: one lane (two for T = 16) owns one (node, head) pair outright: its T q/k/v vectors
-//     are T contiguous 48-byte records, the T x T scores, normalisers and the context run with no
-//     cross-lane traffic, and the d_k outputs leave as one vector store.
+//     q, k and v vectors of ONE head; they go to a wave-private LDS table [4][64 rows][q|k|v].
+//   attention: LP lanes (1 for T <= 6, 2 for T = 8 / 12, 4 for T = 16) own one (node, head) pair and
+//     split its queries; the pair's T q/k/v vectors are T contiguous 48-byte records, keys are taken
+//     in chunks of <= 8 (plain sums of exp: chunking needs no rescaling), the partial results of the
+//     LP lanes meet through the table, and the d_k outputs leave as one vector store.
 #include "common.h"
 
 namespace {
@@ -25,8 +28,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int kRows = 128;
-constexpr int kBT = 8;
+constexpr int kRows = 64;
+constexpr int kBT = 4;
 constexpr int kRec = 48;   // bytes of one (row, 4-column group) record: q[4] | k[4] | v[4]
 
 struct Pieces {
@@ -52,19 +55,18 @@ __device__ __forceinline__ int swz(int row) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Padding of a wave's q|k|v table, found by enumerating the bank sets of the attention phase's vector
-// reads (one lane per (node, head) pair; ds_read_b128 lane groups {0-3, 12-15, 20-27}, ...): without
-// it the 6144-byte head-group stride and the T*48-byte node stride are multiples of 256 bytes for
-// T = 8, 16 and every pair of a lane group lands on the same banks (8-way; 4-way for the other T).
-// kPadNode bytes after each node's T records, kPadGroup bytes after each 4-column group.
-// Conflict-free for every T below except T = 2 (2-way; a per-node pad would not fit LDS at d = 64).
-__host__ __device__ constexpr int pad_node(int t) { return (t == 6 || t == 8 || t == 16) ? 16 : 0; }
-__host__ __device__ constexpr int pad_group(int t, int dk) {
-  return (t == 1 || t == 3 || t == 5 || t == 8) ? 64 : t == 6 ? 112 : (t == 16 && dk == 4) ? 0 : 16;
-}
+// reads (lanes of a ds_read_b128 group {0-3, 12-15, 20-27}, ... belong to different (node, head)
+// pairs): the 3072-byte head-group stride and, for T = 8 / 16, the T*48-byte node stride are
+// multiples of 256 bytes, so without padding every pair of a lane group lands on the same banks
+// (4-way). pad_node bytes after each node's T records, pad_group bytes after each 4-column group:
+// conflict-free for every T below except T = 2 (2-way).
+__host__ __device__ constexpr int pad_node(int t) { return t == 6 ? 16 : 0; }
+__host__ __device__ constexpr int pad_group(int t) { return (t == 1 || t == 3 || t == 5) ? 64 : t == 6 ? 32 : 16; }
+__host__ __device__ constexpr int lanes_per_pair(int t) { return t == 16 ? 4 : (t == 8 || t == 12) ? 2 : 1; }
 
-// T: intervals (compile time). QSPLIT: lanes per (node, head) pair (2 splits the queries in halves).
-template <int D, int T, int QSPLIT>
-__global__ __launch_bounds__(64 * (D / 16), 1) void ln_mhsa_split_kernel(
+// T: intervals (compile time). LP = lanes_per_pair(T).
+template <int D, int T, int LP>
+__global__ __launch_bounds__(64 * (D / 16), 2) void ln_mhsa_split_kernel(
     const float* __restrict__ x, int64_t ld_n, int64_t ld_t, int64_t n, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, int apply_ln, const float* __restrict__ Wq,
     const float* __restrict__ bq, const float* __restrict__ Wk, const float* __restrict__ bk,
@@ -77,7 +79,7 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void ln_mhsa_split_kernel(
   constexpr int ROWS = NB * T;                  // rows in use
   constexpr int PLANE = kRows * D * 2;
   constexpr int LPR = D / 4, RPP = NT / LPR, NFILL = kRows / RPP;
-  constexpr int PN = pad_node(T), PG = pad_group(T, D / 16);
+  constexpr int PN = pad_node(T), PG = pad_group(T);
   constexpr int GS = kRows * kRec + NB * PN + PG;   // bytes of one 4-column group of the table
   constexpr int QKVW = 4 * GS;                  // bytes of one wave's q|k|v table
   typedef float vec __attribute__((ext_vector_type(DK)));
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void ln_mhsa_split_kernel(
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* const Yp = lds;                                     // 3 images
   char* const QKV = lds + 3 * PLANE;                        // NW tables
-  float2* const rstat = reinterpret_cast<float2*>(QKV + NW * QKVW);   // [128] (mean_r, M2_r)
+  float2* const rstat = reinterpret_cast<float2*>(QKV + NW * QKVW);   // [64] (mean_r, M2_r)
   float2* const nstat = rstat + kRows;                      // [NB] (mean, rstd)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -236,54 +238,64 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void ln_mhsa_split_kernel(
 
     // ---- attention of each (node, head) pair of this wave's heads
     constexpr int PAIRS = NB * HPW;
-    constexpr int LSTEP = 64 / QSPLIT;
-    constexpr int TQ = T / QSPLIT;            // queries per lane
-    for (int p = lane / QSPLIT; p < PAIRS; p += LSTEP) {
+    constexpr int LSTEP = 64 / LP;
+    constexpr int TQ = T / LP;                       // queries per lane
+    constexpr int KC = T <= 8 ? T : T / 2;           // keys per chunk
+    static_assert(T % LP == 0 && T % KC == 0 && LP - 1 < TQ + (LP == 1), "query / key split");
+    const int part = lane % LP;
+#pragma unroll 1
+    for (int p = lane / LP; p < PAIRS; p += LSTEP) {
       const int hl = p % HPW, nb = p / HPW;
-      const int half = lane % QSPLIT;
-      const char* base = tab + ((hl * DK) >> 2) * GS + nb * (T * kRec + PN) + ((hl * DK) & 3) * 4;
-      vec k[T], v[T];
+      char* base = tab + ((hl * DK) >> 2) * GS + nb * (T * kRec + PN) + ((hl * DK) & 3) * 4;
+      vec qv[TQ], ctx[TQ];
+      float rs[TQ];
 #pragma unroll
-      for (int s = 0; s < T; ++s) {
-        k[s] = *reinterpret_cast<const vec*>(base + s * kRec + 16);
-        v[s] = *reinterpret_cast<const vec*>(base + s * kRec + 32);
+      for (int i = 0; i < TQ; ++i) {
+        qv[i] = *reinterpret_cast<const vec*>(base + (part * TQ + i) * kRec) * scale;
+        ctx[i] = (vec)(0.f);
+        rs[i] = 0.f;
+      }
+#pragma unroll
+      for (int ch = 0; ch < T / KC; ++ch) {
+        vec k[KC], v[KC];
+#pragma unroll
+        for (int s = 0; s < KC; ++s) {
+          k[s] = *reinterpret_cast<const vec*>(base + (ch * KC + s) * kRec + 16);
+          v[s] = *reinterpret_cast<const vec*>(base + (ch * KC + s) * kRec + 32);
+        }
+#pragma unroll
+        for (int i = 0; i < TQ; ++i)
+#pragma unroll
+          for (int s = 0; s < KC; ++s) {
+            float pd = qv[i][0] * k[s][0];
+#pragma unroll
+            for (int c = 1; c < DK; ++c) pd = fmaf(qv[i][c], k[s][c], pd);
+            const float e = __expf(pd);
+            rs[i] += e;
+            ctx[i] += e * v[s];
+          }
       }
       vec o = (vec)(0.f);
 #pragma unroll
-      for (int i = 0; i < TQ; ++i) {
-        const int tq = half * TQ + i;
-        const vec qv = *reinterpret_cast<const vec*>(base + tq * kRec) * scale;
-        vec ctx = (vec)(0.f);
-        float rs = 0.f;
-#pragma unroll
-        for (int s = 0; s < T; ++s) {
-          float pd = qv[0] * k[s][0];
-#pragma unroll
-          for (int c = 1; c < DK; ++c) pd = fmaf(qv[c], k[s][c], pd);
-          const float e = __expf(pd);
-          rs += e;
-          ctx += e * v[s];
-        }
-        o += ctx * __builtin_amdgcn_rcpf(rs + 1e-8f);
-      }
-      if (QSPLIT == 2) {
-        // The other half's queries sit in lane ^ 1. The partial sums meet through the wave's own table:
-        // the odd lane parks its o in the q slot of the pair's first record (every q of the pair has been
-        // read by now: LDS operations of a wave complete in issue order) and the even lane adds it to its
-        // own. Cross-lane forms measured WRONG here on ROCm 7.2 / gfx950: the update_dpp
-        // loop was miscompiled (two DPP instructions for four components) and __shfl_xor (ds_bpermute)
-        // returned stale values in ~1e-4 of the pairs with two workgroups per CU.
-        char* slot = const_cast<char*>(base);
+      for (int i = 0; i < TQ; ++i) o += ctx[i] * __builtin_amdgcn_rcpf(rs[i] + 1e-8f);
+      if (LP > 1) {
+        // The LP partial sums meet through the wave's own table: lane `part` > 0 parks its o in the q slot
+        // of the pair's record `part` (a query of lane 0, read into qv long ago: LDS operations of a wave
+        // complete in issue order), lane 0 adds them in a fixed order. Cross-lane forms measured WRONG
+        // here on ROCm 7.2 / gfx950: an update_dpp loop was miscompiled (two DPP instructions for four
+        // components) and __shfl_xor (ds_bpermute) returned stale values in ~1e-4 of the pairs with
+        // several workgroups per CU.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (half == 1) *reinterpret_cast<vec*>(slot) = o;
+        if (part > 0) *reinterpret_cast<vec*>(base + part * kRec) = o;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        o += *reinterpret_cast<const vec*>(slot);   // meaningful on the even lane, which stores
+#pragma unroll
+        for (int j = 1; j < LP; ++j) o += *reinterpret_cast<const vec*>(base + j * kRec);   // meaningful on lane 0
       }
       const int64_t node = node0 + nb;
-      if (half == 0 && node < n) *reinterpret_cast<vec*>(out + node * ld_out + 16 * wave + hl * DK) = o * inv_t;
+      if (part == 0 && node < n) *reinterpret_cast<vec*>(out + node * ld_out + 16 * wave + hl * DK) = o * inv_t;
     }
     // the next tile's products overwrite the table only after its own barriers; its fill overwrites
     // the y images, which every wave finished reading before the barrier above
@@ -299,20 +311,21 @@ bool mhsa_split_supported(int d, int t, int heads) {
   return (t >= 1 && t <= 6) || t == 8 || t == 12 || t == 16;
 }
 
-template <int D, int T, int QSPLIT>
+template <int D, int T>
 static int launch_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, const float* gamma, const float* beta,
                         float eps, int apply_ln, const float* Wq, const float* bq, const float* Wk, const float* bk,
                         const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s) {
   constexpr int NW = D / 16, NB = kRows / T;
-  constexpr int GS = kRows * kRec + NB * pad_node(T) + pad_group(T, D / 16);
+  constexpr int LP = lanes_per_pair(T);
+  constexpr int GS = kRows * kRec + NB * pad_node(T) + pad_group(T);
   const size_t lds = (size_t)3 * kRows * D * 2 + (size_t)NW * 4 * GS + (size_t)(kRows + NB) * sizeof(float2);
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&ln_mhsa_split_kernel<D, T, QSPLIT>), lds)) return rc;
-  const int per_cu = D == 64 ? 1 : 2;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&ln_mhsa_split_kernel<D, T, LP>), lds)) return rc;
+  const int per_cu = D == 64 ? 2 : 4;             // ~76 KB / ~38 KB of LDS and <= 256 registers: two waves per SIMD
   const int64_t n_tiles = (n + NB - 1) / NB;
   const int64_t want = (int64_t)cu_count_current() * per_cu;
   const int64_t blocks = n_tiles < want ? n_tiles : want;
   ProfileScope prof(kProfMhsa, s, n, T);
-  hipLaunchKernelGGL((ln_mhsa_split_kernel<D, T, QSPLIT>), dim3((unsigned)blocks), dim3(64 * NW), lds, s, x, ld_n, ld_t, n,
+  hipLaunchKernelGGL((ln_mhsa_split_kernel<D, T, LP>), dim3((unsigned)blocks), dim3(64 * NW), lds, s, x, ld_n, ld_t, n,
                      gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, n_tiles);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
@@ -322,11 +335,11 @@ template <int D>
 static int dispatch_t(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, const float* gamma,
                       const float* beta, float eps, int apply_ln, const float* Wq, const float* bq, const float* Wk,
                       const float* bk, const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s) {
-#define SAGNN_T_CASE(TT, QS) \
-  case TT: return launch_split<D, TT, QS>(x, ld_n, ld_t, n, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
+#define SAGNN_T_CASE(TT) \
+  case TT: return launch_split<D, TT>(x, ld_n, ld_t, n, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
   switch (t) {
-    SAGNN_T_CASE(1, 1) SAGNN_T_CASE(2, 1) SAGNN_T_CASE(3, 1) SAGNN_T_CASE(4, 1) SAGNN_T_CASE(5, 1) SAGNN_T_CASE(6, 1)
-    SAGNN_T_CASE(8, 1) SAGNN_T_CASE(12, 1) SAGNN_T_CASE(16, 2)
+    SAGNN_T_CASE(1) SAGNN_T_CASE(2) SAGNN_T_CASE(3) SAGNN_T_CASE(4) SAGNN_T_CASE(5) SAGNN_T_CASE(6)
+    SAGNN_T_CASE(8) SAGNN_T_CASE(12) SAGNN_T_CASE(16)
     default: return fail(SAGNN_ERR_DIM, "split attention: t = %d has no specialised kernel", t);
   }
 #undef SAGNN_T_CASE
