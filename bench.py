@@ -254,28 +254,24 @@ def main():
         if world != 1:
             raise SystemExit("--stages train is a single-GPU measurement")
         from sa_gnn_amd import autograd as ag
-        leaves = {}
-        for j in range(t_loc):
-            leaves[f"u{j}"] = emb[j][0].requires_grad_(True)
-            leaves[f"i{j}"] = emb[j][1].requires_grad_(True)
+        leaves = {"uEmbed": torch.stack([e[0] for e in emb]).requires_grad_(True),      # [T, U, d] / [T, I, d] as the model holds them
+                  "iEmbed": torch.stack([e[1] for e in emb]).requires_grad_(True)}
+        emb.clear()
+        torch.cuda.empty_cache()
         for tag, p in (("U", prm[0]), ("I", prm[1])):
             for k, v in p.items():
                 if tag == "I" and k in ("lstm_W", "lstm_b"):
                     continue                              # the cell is shared: one leaf
                 leaves[f"{tag}.{k}"] = v.requires_grad_(True)
-        opt = ops.Adam(leaves, lr=1e-3, decay=0.96, decay_step=19, reg=1e-2,
-                       reg_names=[k for k in leaves if k[0] in "ui"])
+        opt = ops.Adam(leaves, lr=1e-3, decay=0.96, decay_step=19, reg=1e-2, reg_names=["uEmbed", "iEmbed"])
+        pl_u, pl_i = [pp[0] for pp in plans], [pp[1] for pp in plans]
 
         def step():                                       # noqa: F811  (training step replaces the forward step)
             for v in leaves.values():
                 v.grad = None
-            us, its = [], []
-            for j in range(t_loc):
-                uo, io = ag.gnn_interval(leaves[f"u{j}"], leaves[f"i{j}"], plans[j][0], plans[j][1], L, 0.5)
-                us.append(uo)
-                its.append(io)
-            fu = ag.interval_fusion(torch.stack(us).permute(1, 0, 2), prm[0], heads)
-            fi = ag.interval_fusion(torch.stack(its).permute(1, 0, 2), prm[1], heads)
+            us, its = ag.gnn_stack(leaves["uEmbed"], leaves["iEmbed"], pl_u, pl_i, L, 0.5)      # [T, N, d] slabs, no stack copy
+            fu = ag.interval_fusion(us.permute(1, 0, 2), prm[0], heads)
+            fi = ag.interval_fusion(its.permute(1, 0, 2), prm[1], heads)
             (fu.sum() + fi.sum()).backward()
             opt.step({k: v.grad for k, v in leaves.items()})
             state["final"] = [fu.detach(), fi.detach()]

@@ -49,6 +49,61 @@ def gnn_interval(u0, i0, plan_user, plan_item, n_layers: int, leaky: float):
     return GnnIntervalFn.apply(u0, i0, plan_user, plan_item, n_layers, leaky)
 
 
+class GnnStackFn(torch.autograd.Function):
+    """(uEmbed [T, U, d], iEmbed [T, I, d]) -> (user slab [T, U, d], item slab [T, I, d]): the whole loop of
+    model.py:118-129 as ONE autograd node. Interval outputs are written straight into the slabs the fusion reads
+    as [N, T, d] views (no torch.stack copy), and the backward hands each interval's gradient slice — whatever
+    its row stride — to sagnn_gnn_interval_bwd_f32, writing the embedding gradients in place."""
+
+    @staticmethod
+    def forward(ctx, u_embed, i_embed, plans_user, plans_item, n_layers, leaky):
+        T, U, d = u_embed.shape
+        I = i_embed.shape[1]
+        dev = u_embed.device
+        ue, ie = u_embed.detach(), i_embed.detach()
+        out_u = torch.empty((T, U, d), dtype=torch.float32, device=dev)
+        out_i = torch.empty((T, I, d), dtype=torch.float32, device=dev)
+        mask_u = torch.empty((T, n_layers, U, d // 4), dtype=torch.uint8, device=dev)
+        mask_i = torch.empty((T, n_layers, I, d // 4), dtype=torch.uint8, device=dev)
+        scr_u = torch.empty((2, U, d), dtype=torch.float32, device=dev) if n_layers > 1 else None
+        scr_i = torch.empty((2, I, d), dtype=torch.float32, device=dev) if n_layers > 1 else None
+        for k in range(T):
+            ops.gnn_interval(plans_user[k], plans_item[k], ue[k], ie[k], n_layers, leaky, out_u[k], out_i[k], scr_u, scr_i,
+                             mask_u=mask_u[k], mask_i=mask_i[k])
+        ctx.save_for_backward(mask_u, mask_i)
+        ctx.plans = (plans_user, plans_item)
+        ctx.cfg = (n_layers, leaky)
+        return out_u, out_i
+
+    @staticmethod
+    def backward(ctx, g_user, g_item):
+        mask_u, mask_i = ctx.saved_tensors
+        plans_user, plans_item = ctx.plans
+        n_layers, leaky = ctx.cfg
+        T, _, U, dq = mask_u.shape
+        I, d, dev = mask_i.shape[2], dq * 4, mask_u.device
+        if g_user is None:
+            g_user = torch.zeros((T, U, d), dtype=torch.float32, device=dev)
+        if g_item is None:
+            g_item = torch.zeros((T, I, d), dtype=torch.float32, device=dev)
+        if g_user.stride(2) != 1:
+            g_user = g_user.contiguous()
+        if g_item.stride(2) != 1:
+            g_item = g_item.contiguous()
+        du = torch.empty((T, U, d), dtype=torch.float32, device=dev)
+        di = torch.empty((T, I, d), dtype=torch.float32, device=dev)
+        scr_u = torch.empty((4, U, d), dtype=torch.float32, device=dev)
+        scr_i = torch.empty((4, I, d), dtype=torch.float32, device=dev)
+        for k in range(T):
+            ops.gnn_interval_bwd(plans_user[k], plans_item[k], g_user[k], g_item[k], n_layers, leaky, mask_u[k], mask_i[k],
+                                 grad_u0=du[k], grad_i0=di[k], scratch_u=scr_u, scratch_i=scr_i)
+        return du, di, None, None, None, None
+
+
+def gnn_stack(u_embed, i_embed, plans_user, plans_item, n_layers: int, leaky: float):
+    return GnnStackFn.apply(u_embed, i_embed, plans_user, plans_item, n_layers, leaky)
+
+
 def _split_qkv_grads(dWqkv, dbqkv, d):
     """[d, 3d] / [3d] -> (dWq, dbq, dWk, dbk, dWv, dbv)."""
     out = ()

@@ -78,12 +78,34 @@ __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (HI > LO) static_for_impl<LO>(static_cast<F&&>(f), std::make_integer_sequence<int, HI - LO>{});
 }
 
+// The interleaved operation list of `step`: kGateOps gate-math operations of one batch tile followed by
+// kXOps operations that split one 16-row pass of the next step's x into its LDS images. Transcendentals
+// take two issue slots of four cycles, everything else one; operations are dealt to the MFMA slots by
+// cumulative cost, so that no slot carries two transcendentals.
+constexpr int kGateOps = 127, kXOps = 20;
+__host__ __device__ constexpr int op_cost(int k) {
+  if (k >= 1 && k < 17) return 0;   // retired operations (kept so the numbering of the stages stays put)
+  return ((k >= 17 && k < 33) || (k >= 49 && k < 65) || (k >= 81 && k < 85) || (k >= 89 && k < 93)) ? 2 : 1;
+}
+__host__ __device__ constexpr int op_cum(int k) {
+  int c = 0;
+  for (int j = 0; j < k; ++j) c += op_cost(j);
+  return c;
+}
+// first of `nops` operations that belongs to MFMA slot i or a later one (slot of k = cum(k) * nm / total)
+__host__ __device__ constexpr int first_op_of_slot(int i, int nm, int nops) {
+  const int tot = op_cum(nops);
+  int k = 0;
+  while (k < nops && op_cum(k) * nm / tot < i) ++k;
+  return k;
+}
+
 __device__ __forceinline__ void lds_barrier() {
   // LDS traffic only: outstanding global loads (the x prefetch) and stores stay in flight across it
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int D, bool SAVE>
+template <int D, bool SAVE, bool DROP>
 __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
     const float* __restrict__ x, int64_t ld_n, int64_t ld_t, int64_t n, int t, const float* __restrict__ W,
     const float* __restrict__ bias, float forget_bias, const float* __restrict__ drop, float* __restrict__ h_out,
@@ -118,7 +140,8 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
     for (int ks = 0; ks < KS; ++ks) {
       Pieces pc[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pc[j] = split3(W[(size_t)(32 * ks + 8 * q + j) * NC + g * D + 16 * wave + m]);
+      for (int j = 0; j < 8; ++j)   // column scale of the gate's non-linearity folded into W (see bc below)
+        pc[j] = split3(W[(size_t)(32 * ks + 8 * q + j) * NC + g * D + 16 * wave + m] * (g == 1 ? 2.f * kL2E : -kL2E));
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         wf[g][ks][0][e] = pack_hi(pc[2 * e].p1, pc[2 * e + 1].p1);
@@ -126,8 +149,10 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
         wf[g][ks][2][e] = pack_hi(pc[2 * e].p3, pc[2 * e + 1].p3);
       }
     }
-  // gate non-linearities as exp2(fma(acc, k, k * bias)): bias, forget bias and log2(e) ride on one fma
-  float bc[4][4];
+  // Gate non-linearities are evaluated as exp2(t), t = k (pre-activation + bias), k = -log2(e) for the
+  // sigmoids and 2 log2(e) for tanh(j): k is folded into this wave's columns of W (one rounding of each
+  // weight, 2^-24 relative) and k * bias is what the accumulators start from, so t leaves the MFMAs ready.
+  f32x4 bc[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -194,7 +219,6 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
     write_x(0);
     lds_barrier();
 
-    const float no_drop = drop ? 0.f : 1.f;   // a missing mask reads 0 through the empty descriptor
 
     // One step, hand-scheduled. The MFMAs of batch tile bt (6 piece products x 4 gates x k-steps,
     // one accumulator chain per gate) are issued one at a time, and after each one a slice of the
@@ -207,16 +231,18 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
       constexpr bool RECUR = decltype(recur_c)::value;
       constexpr int KSN = RECUR ? KS : KSH;           // k-steps per tile
       constexpr int NM = 24 * KSN;                    // MFMAs per tile
-      constexpr int kOps = 127;
       const char* const Xcur = Xp + (ts & 1) * 3 * PLANE;
       const char* const Hcur = Hp + (ts & 1) * 3 * PLANE;
       char* const Hnxt = Hp + ((ts & 1) ^ 1) * 3 * PLANE;
+      char* const Xnxt = Xp + ((ts & 1) ^ 1) * 3 * PLANE;
       // lane-derived LDS offsets recomputed per step (left loop-invariant the compiler hoists and spills them)
-      int m_ = m, q_ = q;
-      asm volatile("" : "+v"(m_), "+v"(q_));
+      int m_ = m, q_ = q, fr_ = fr, fc4_ = fc4;
+      asm volatile("" : "+v"(m_), "+v"(q_), "+v"(fr_), "+v"(fc4_));
       const int hid = 16 * wave + 4 * q_;
 
       f32x4 acc[4];                    // tile in flight
+      float xp1[4], xr1[4], xp2[4], xp3[4];   // pieces of the x pass being written
+      int xw0[2], xw1[2], xw2[2], xoff;
       f32x4 ga[4];                     // pre-activations of the tile whose gate math is being interleaved
       f32x4 dv;                        // dropout scale of that tile
       float tt[4][4], pr[4], cn[4], u[4], hn[4], hv[4], p1[4], r1[4], p2[4], p3[4];
@@ -238,13 +264,11 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
         const int row = PB * 16 + m_;
         if constexpr (K == 0) {
           const int e_td = (row * t + ts) * D + hid;
-          dv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, e_td * 4, 0, 0));
-        } else if constexpr (K < 17) {          // 1..16: scaled pre-activation + bias
-          constexpr int k = K - 1, g = k >> 2, r = k & 3;
-          tt[g][r] = fmaf(ga[g][r], g == 1 ? 2.f * kL2E : -kL2E, bc[g][r]);
+          if constexpr (DROP) dv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, e_td * 4, 0, 0));
+        } else if constexpr (K < 17) {          // 1..16: retired (scale and bias now ride in W and the accumulator)
         } else if constexpr (K < 33) {
           constexpr int k = K - 17, g = k >> 2, r = k & 3;
-          tt[g][r] = __builtin_amdgcn_exp2f(tt[g][r]);
+          tt[g][r] = __builtin_amdgcn_exp2f(ga[g][r]);
         } else if constexpr (K < 49) {
           constexpr int k = K - 33, g = k >> 2, r = k & 3;
           tt[g][r] = 1.f + tt[g][r];
@@ -270,7 +294,8 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
         } else if constexpr (K < 101) {
           hn[K - 97] = u[K - 97] * tt[3][K - 97];
         } else if constexpr (K < 105) {
-          hv[K - 101] = hn[K - 101] * (dv[K - 101] + no_drop);
+          if constexpr (DROP) hv[K - 101] = hn[K - 101] * dv[K - 101];
+          else hv[K - 101] = hn[K - 101];
         } else if constexpr (K < 109) {
           p1[K - 105] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, hn[K - 105]) & 0xFFFF0000u);
         } else if constexpr (K < 113) {
@@ -300,7 +325,7 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
           __builtin_amdgcn_raw_buffer_store_b128(hvv, rs_h, (row * (int)ld_h + ts * D + hid) * 4, 0, 0);
           c[PB] = f32x4{cn[0], cn[1], cn[2], cn[3]};
         } else if constexpr (K == 126) {
-          if (SAVE) {
+          if constexpr (SAVE) {
             const int e_td = (row * t + ts) * D + hid;
             const int go_ = (row * t + ts) * NC + hid;
 #pragma unroll
@@ -313,6 +338,39 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
                               __builtin_bit_cast(int, cn[3])};
             __builtin_amdgcn_raw_buffer_store_b128(cv, rs_c, e_td * 4, 0, 0);
           }
+        } else {
+          // ---- K >= kGateOps: two 16-row passes of the next step's x, split and stored. They ride with the
+          // LAST three tiles' gate math (tile PB + 1 carries passes 2 (PB - (kBT - 4)) and + 1), thousands of
+          // cycles after their loads were issued at the top of the step: placed right behind the loads, the
+          // first of them parked the whole MFMA stream on vmcnt. At the last step xr is stale and the target
+          // buffer is never read: harmless, and branch-free.
+          constexpr int XP = 2 * (PB - (kBT - 4)) + (K - kGateOps) / kXOps;     // pass 0 .. NFILL-1
+          constexpr int X = (K - kGateOps) % kXOps;
+          const float xv[4] = {xr[XP].x, xr[XP].y, xr[XP].z, xr[XP].w};
+          const int xrow = XP * RPP + fr_;
+          if constexpr (X < 4) {
+            xp1[X] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, xv[X]) & 0xFFFF0000u);
+          } else if constexpr (X < 8) {
+            xr1[X - 4] = xv[X - 4] - xp1[X - 4];
+          } else if constexpr (X < 12) {
+            xp2[X - 8] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, xr1[X - 8]) & 0xFFFF0000u);
+          } else if constexpr (X < 16) {
+            xp3[X - 12] = xr1[X - 12] - xp2[X - 12];
+          } else if constexpr (X == 16) {
+            xw0[0] = pack_hi(xp1[0], xp1[1]);
+            xw0[1] = pack_hi(xp1[2], xp1[3]);
+          } else if constexpr (X == 17) {
+            xw1[0] = pack_hi(xp2[0], xp2[1]);
+            xw1[1] = pack_hi(xp2[2], xp2[3]);
+          } else if constexpr (X == 18) {
+            xw2[0] = pack_hi(xp3[0], xp3[1]);
+            xw2[1] = pack_hi(xp3[2], xp3[3]);
+            xoff = xrow * (D * 2) + (((fc4_ >> 3) ^ swz<D>(xrow)) << 4) + ((fc4_ >> 2) & 1) * 8;
+          } else {
+            *reinterpret_cast<i32x2*>(Xnxt + xoff) = i32x2{xw0[0], xw0[1]};
+            *reinterpret_cast<i32x2*>(Xnxt + PLANE + xoff) = i32x2{xw1[0], xw1[1]};
+            *reinterpret_cast<i32x2*>(Xnxt + 2 * PLANE + xoff) = i32x2{xw2[0], xw2[1]};
+          }
         }
         (void)R;
         (void)G;
@@ -320,7 +378,8 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
       // MFMA number I of tile BT, then the slice [I kOps / NM, (I+1) kOps / NM) of tile BT-1's gate math
       auto slot = [&](auto bt_c, auto i_c) {
         constexpr int BT = decltype(bt_c)::value, I = decltype(i_c)::value;
-        constexpr int ks = I / 24, g = (I % 24) / 6, term = I % 6;
+        // gate index fastest: consecutive MFMAs go to four different accumulator chains
+        constexpr int ks = I / 24, term = (I % 24) / 4, g = I % 4;
         constexpr int cur = (BT * KSN + ks) & 1;
         if constexpr (I % 24 == 0) {               // request the next k-step's (or the next tile's first) fragments
           if constexpr (ks + 1 < KSN) read_b(BT, ks + 1, bf[cur ^ 1]);
@@ -329,11 +388,12 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
         // piece products, smallest first: a3 b1, a1 b3, a2 b2, a2 b1, a1 b2, a1 b1
         constexpr int ai = term == 0 ? 2 : (term == 2 || term == 3) ? 1 : 0;
         constexpr int bi = term == 1 ? 2 : (term == 2 || term == 4) ? 1 : 0;
-        const f32x4 cin = (ks == 0 && term == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[g];
+        const f32x4 cin = (ks == 0 && term == 0) ? bc[g] : acc[g];
         acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[g][ks][ai]),
                                                          __builtin_bit_cast(bf16x8, bf[cur][bi]), cin, 0, 0, 0);
         if constexpr (BT > 0) {
-          constexpr int lo = I * kOps / NM, hi = (I + 1) * kOps / NM;
+          constexpr int NOPS = kGateOps + (BT >= kBT - 3 ? 2 * kXOps : 0);
+          constexpr int lo = first_op_of_slot(I, NM, NOPS), hi = first_op_of_slot(I + 1, NM, NOPS);
           static_for<lo, hi>([&](auto k_c) { gate_op(std::integral_constant<int, BT - 1>{}, k_c); });
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -346,17 +406,16 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_split_kernel(
       };
       read_b(0, 0, bf[0]);
       static_for<0, kBT>(tile);
-      static_for<0, kOps>([&](auto k_c) { gate_op(std::integral_constant<int, kBT - 1>{}, k_c); });   // the last tile's gates
+      // the last tile's gates: the only part of the step the MFMAs do not cover
+      static_for<0, kGateOps>([&](auto k_c) { gate_op(std::integral_constant<int, kBT - 1>{}, k_c); });
     };
 
     for (int ts = 0; ts < t; ++ts) {
       if (ts + 1 < t) fetch_x(ts + 1);               // in flight under this step
       if (ts > 0 || h_init != nullptr) step(std::true_type{}, ts);
       else step(std::false_type{}, ts);               // zero initial state: the h half contributes nothing
-      if (ts + 1 < t) {
-        write_x((ts + 1) & 1);   // x_{ts+1} into the other buffer: its loads were issued at the top of the step
-        lds_barrier();           // x_{ts+1} and every wave's columns of h_{ts+1} are in place; x_ts / h_ts are free
-      }
+      // x_{ts+1} went into the other buffer inside the step (its loads were issued at the top of it)
+      if (ts + 1 < t) lds_barrier();   // x_{ts+1} and every wave's columns of h_{ts+1} are in place; x_ts / h_ts are free
     }
     if (c_final) {
 #pragma unroll
@@ -373,19 +432,19 @@ namespace sagnn {
 
 bool lstm_split_supported(int d) { return d == 32 || d == 64; }
 
-template <int D, bool SAVE>
+template <int D, bool SAVE, bool DROP>
 static int launch_lstm_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, const float* W,
                              const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
                              float* gates_out, float* c_out, const float* h_init, int64_t ld_hi, const float* c_init,
                              float* c_final, hipStream_t s) {
   const size_t lds = (size_t)12 * kRows * D * 2;  // x and h: 2 x 3 images each (144 KB at D = 64)
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_fwd_split_kernel<D, SAVE>), lds)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_fwd_split_kernel<D, SAVE, DROP>), lds)) return rc;
   const int per_cu = D == 64 ? 1 : 2;             // D = 32: 72 KB and 2 waves per workgroup
   const int64_t n_tiles = (n + kRows - 1) / kRows;
   const int64_t want = (int64_t)cu_count_current() * per_cu;
   const int64_t blocks = n_tiles < want ? n_tiles : want;
   ProfileScope prof(kProfLstm, s, n, t);
-  hipLaunchKernelGGL((lstm_fwd_split_kernel<D, SAVE>), dim3((unsigned)blocks), dim3(64 * (D / 16)), lds, s, x, ld_n, ld_t,
+  hipLaunchKernelGGL((lstm_fwd_split_kernel<D, SAVE, DROP>), dim3((unsigned)blocks), dim3(64 * (D / 16)), lds, s, x, ld_n, ld_t,
                      n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, n_tiles, h_init, ld_hi, c_init, c_final);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
@@ -400,8 +459,14 @@ int lstm_fwd_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t,
   if (ld_h >= (1 << 22) || (int64_t)t * d >= (1 << 18))
     return fail(SAGNN_ERR_ARG, "split LSTM: output row stride must stay below 2^22 floats and t*d below 2^18");
   if (ld_h < (int64_t)t * d) return fail(SAGNN_ERR_ARG, "split LSTM: ld_h = %lld < t*d", (long long)ld_h);
-#define SAGNN_LSTM_GO(DD, SV) \
-  return launch_lstm_split<DD, SV>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, h_init, ld_hi, c_init, c_final, s)
+#define SAGNN_LSTM_GO(DD, SV)                                                                                        \
+  do {                                                                                                               \
+    if (drop)                                                                                                        \
+      return launch_lstm_split<DD, SV, true>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, \
+                                             h_init, ld_hi, c_init, c_final, s);                                     \
+    return launch_lstm_split<DD, SV, false>(x, ld_n, ld_t, n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out,  \
+                                            h_init, ld_hi, c_init, c_final, s);                                      \
+  } while (0)
   if (d == 64 && save) SAGNN_LSTM_GO(64, true);
   if (d == 64) SAGNN_LSTM_GO(64, false);
   if (d == 32 && save) SAGNN_LSTM_GO(32, true);

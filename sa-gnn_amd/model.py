@@ -296,15 +296,12 @@ class Recommender:
         term, applied inside the optimiser step)."""
         T, L, d, heads, leaky = args.graphNum, args.gnn_layer, args.latdim, args.num_attention_heads, NNs.leaky
         keep = args.keepRate if keep_rate is None else keep_rate
-        uv, iv = [], []
-        for k in range(T):
-            u, i = ag.gnn_interval(self.uEmbed[k], self.iEmbed[k], self.subAdj[k].plan, self.subTpAdj[k].plan, L, leaky)
-            uv.append(u)
-            iv.append(i)
+        # one autograd node for the whole interval loop; uv / iv are [T, N, d] slabs written in place
+        uv, iv = ag.gnn_stack(self.uEmbed, self.iEmbed, [a.plan for a in self.subAdj], [a.plan for a in self.subTpAdj], L, leaky)
         finals = []
         for xs, (gamma, beta), att, key in ((uv, self.ln[0], self.multihead_self_attention0, "drop_u"),
                                             (iv, self.ln[1], self.multihead_self_attention1, "drop_i")):
-            x = torch.stack(xs, 0).permute(1, 0, 2)                       # [N, T, d] view of [T, N, d]
+            x = xs.permute(1, 0, 2)                                       # [N, T, d] view of [T, N, d]: no copy
             drop = batch.get(key)
             if drop is None and keep < 1.0:                               # DropoutWrapper(output_keep_prob)
                 drop = (torch.rand((x.shape[0], T, d), device=self.device) < keep).float() / keep
