@@ -368,14 +368,18 @@ def main():
     stage_ms = {name: sum(r[1] for r in rec if r[0] == kk) / a.steps
                 for kk, name in ((0, "spmm_rows"), (1, "spmm_fixup"), (2, "lstm"), (3, "layernorm"), (4, "mhsa_mean"))}
     traffic, traffic_source = None, None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
+    import glob
+    for tpath in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json"))):
         try:
             tj = json.load(open(tpath))
             if tj.get("workload") == a.workload and tj.get("scale", 1.0) == a.scale and a.zipf == tj.get("zipf", 0.8):
                 traffic = tj.get("bytes_per_launch")
-                traffic_source = ("recorded: profiles/hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
-                                  "earlier run of this command, guide corrections applied) — NOT measured in this run")
+                traffic_source = (f"recorded: profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an "
+                                  "earlier run of this workload's SpMM launches, guide corrections applied; mean of the two "
+                                  "directions) — NOT measured in this run")
+                for k_, v_ in (tj.get("by_direction") or {}).items():
+                    if side.get(k_):
+                        side[k_]["traffic"] = v_.get("bytes_per_launch")
         except Exception:
             traffic = None
 
