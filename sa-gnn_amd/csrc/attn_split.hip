@@ -48,6 +48,7 @@ __device__ __forceinline__ int pack_hi(float lo, float hi) {
 }
 template <int D>
 __device__ __forceinline__ int swz(int row) {
+  if (D == 128) return row & 15;      // 256-byte rows all start on bank 0
   if (D == 64) return (row >> 1) & 7;
   const int g = (row >> 2) & 3;
   return (0x78 >> (2 * g)) & 3;
@@ -62,17 +63,42 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // conflict-free for every T below except T = 2 (2-way).
 __host__ __device__ constexpr int pad_node(int t) { return t == 6 ? 16 : 0; }
 __host__ __device__ constexpr int pad_group(int t) { return (t == 1 || t == 3 || t == 5) ? 64 : t == 6 ? 32 : 16; }
-__host__ __device__ constexpr int lanes_per_pair(int t) { return t == 16 ? 4 : (t == 8 || t == 12) ? 2 : 1; }
+__host__ __device__ constexpr int lanes_per_pair(int t, int d) {
+  if (d == 128) return (t % 4 == 0) ? 4 : (t % 2 == 0) ? 2 : 1;   // d_k = 8: two heads per wave, fewer pairs per tile
+  return t == 16 ? 4 : (t == 8 || t == 12) ? 2 : 1;
+}
 
-// T: intervals (compile time). LP = lanes_per_pair(T).
+// d_k floats of a q / k / v vector: one 4-column group of the table, or (d_k = 8) two neighbouring groups
+template <int DK>
+struct HeadVec {
+  typedef float type __attribute__((ext_vector_type(DK)));
+  static __device__ __forceinline__ type load(const char* p, int gs) { return *reinterpret_cast<const type*>(p); }
+  static __device__ __forceinline__ void store(char* p, int gs, type v) { *reinterpret_cast<type*>(p) = v; }
+};
+template <>
+struct HeadVec<8> {
+  typedef float type __attribute__((ext_vector_type(8)));
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ type load(const char* p, int gs) {
+    const f4 a = *reinterpret_cast<const f4*>(p), b = *reinterpret_cast<const f4*>(p + gs);
+    return type{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  }
+  static __device__ __forceinline__ void store(char* p, int gs, type v) {
+    *reinterpret_cast<f4*>(p) = f4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f4*>(p + gs) = f4{v[4], v[5], v[6], v[7]};
+  }
+};
+
+// T: intervals (compile time). LP = lanes_per_pair(T, D). d = 128: a workgroup (4 waves) covers 64 of the 128
+// output columns of each of Q, K, V; blockIdx.y picks the half (the layer norm is evaluated by both).
 template <int D, int T, int LP>
-__global__ __launch_bounds__(64 * (D / 16), 2) void ln_mhsa_split_kernel(
+__global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void ln_mhsa_split_kernel(
     const float* __restrict__ x, int64_t ld_n, int64_t ld_t, int64_t n, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, int apply_ln, const float* __restrict__ Wq,
     const float* __restrict__ bq, const float* __restrict__ Wk, const float* __restrict__ bk,
     const float* __restrict__ Wv, const float* __restrict__ bv, float* __restrict__ out, int64_t ld_out,
     int64_t n_tiles) {
-  constexpr int NW = D / 16, NT = 64 * NW, KS = D / 32;
+  constexpr int NW = D >= 64 ? 4 : D / 16, NT = 64 * NW, KS = D / 32;
   constexpr int DK = D / 16;                    // 16 heads
   constexpr int HPW = 16 / DK;                  // heads per wave
   constexpr int NB = kRows / T;                 // nodes per tile
@@ -82,7 +108,7 @@ __global__ __launch_bounds__(64 * (D / 16), 2) void ln_mhsa_split_kernel(
   constexpr int PN = pad_node(T), PG = pad_group(T);
   constexpr int GS = kRows * kRec + NB * PN + PG;   // bytes of one 4-column group of the table
   constexpr int QKVW = 4 * GS;                  // bytes of one wave's q|k|v table
-  typedef float vec __attribute__((ext_vector_type(DK)));
+  typedef typename HeadVec<DK>::type vec;
 
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* const Yp = lds;                                     // 3 images
@@ -92,7 +118,8 @@ __global__ __launch_bounds__(64 * (D / 16), 2) void ln_mhsa_split_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, q = lane >> 4;
-  const int col0 = 16 * wave + 4 * q;           // this lane's 4 output columns of each of Q, K, V
+  const int cbase = 64 * (int)blockIdx.y + 16 * wave;   // this wave's 16 output columns of each of Q, K, V
+  const int col0 = cbase + 4 * q;               // this lane's 4 of them
   const int fr = tid / LPR, fc4 = (tid % LPR) * 4;
   char* const tab = QKV + wave * QKVW;
 
@@ -106,7 +133,7 @@ __global__ __launch_bounds__(64 * (D / 16), 2) void ln_mhsa_split_kernel(
       for (int ks = 0; ks < KS; ++ks) {
         Pieces pc[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pc[j] = split3(Ws[mat][(size_t)(32 * ks + 8 * q + j) * D + 16 * wave + m]);
+        for (int j = 0; j < 8; ++j) pc[j] = split3(Ws[mat][(size_t)(32 * ks + 8 * q + j) * D + cbase + m]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           wf[mat][ks][0][e] = pack_hi(pc[2 * e].p1, pc[2 * e + 1].p1);
@@ -127,7 +154,7 @@ __global__ __launch_bounds__(64 * (D / 16), 2) void ln_mhsa_split_kernel(
     g4 = *reinterpret_cast<const float4*>(gamma + fc4);
     b4 = *reinterpret_cast<const float4*>(beta + fc4);
   }
-  const float scale = DK == 4 ? 0.5f : 0.70710678118654752440f;   // 1 / sqrt(d_k)
+  const float scale = DK == 4 ? 0.5f : DK == 2 ? 0.70710678118654752440f : 0.35355339059327376220f;   // 1 / sqrt(d_k)
   const float inv_t = 1.f / (float)T;
 
   float4 xr[NFILL];
@@ -241,17 +268,17 @@ __global__ __launch_bounds__(64 * (D / 16), 2) void ln_mhsa_split_kernel(
     constexpr int LSTEP = 64 / LP;
     constexpr int TQ = T / LP;                       // queries per lane
     constexpr int KC = T <= 8 ? T : T / 2;           // keys per chunk
-    static_assert(T % LP == 0 && T % KC == 0 && LP - 1 < TQ + (LP == 1), "query / key split");
+    static_assert(T % LP == 0 && T % KC == 0 && LP <= T, "query / key split");
     const int part = lane % LP;
 #pragma unroll 1
     for (int p = lane / LP; p < PAIRS; p += LSTEP) {
       const int hl = p % HPW, nb = p / HPW;
-      char* base = tab + ((hl * DK) >> 2) * GS + nb * (T * kRec + PN) + ((hl * DK) & 3) * 4;
+      char* base = tab + ((hl * DK) >> 2) * GS + nb * (T * kRec + PN) + ((hl * DK) & 3) * 4;   // DK = 8: groups 2 hl, 2 hl + 1
       vec qv[TQ], ctx[TQ];
       float rs[TQ];
 #pragma unroll
       for (int i = 0; i < TQ; ++i) {
-        qv[i] = *reinterpret_cast<const vec*>(base + (part * TQ + i) * kRec) * scale;
+        qv[i] = HeadVec<DK>::load(base + (part * TQ + i) * kRec, GS) * scale;
         ctx[i] = (vec)(0.f);
         rs[i] = 0.f;
       }
@@ -260,8 +287,8 @@ __global__ __launch_bounds__(64 * (D / 16), 2) void ln_mhsa_split_kernel(
         vec k[KC], v[KC];
 #pragma unroll
         for (int s = 0; s < KC; ++s) {
-          k[s] = *reinterpret_cast<const vec*>(base + (ch * KC + s) * kRec + 16);
-          v[s] = *reinterpret_cast<const vec*>(base + (ch * KC + s) * kRec + 32);
+          k[s] = HeadVec<DK>::load(base + (ch * KC + s) * kRec + 16, GS);
+          v[s] = HeadVec<DK>::load(base + (ch * KC + s) * kRec + 32, GS);
         }
 #pragma unroll
         for (int i = 0; i < TQ; ++i)
@@ -280,22 +307,31 @@ __global__ __launch_bounds__(64 * (D / 16), 2) void ln_mhsa_split_kernel(
       for (int i = 0; i < TQ; ++i) o += ctx[i] * __builtin_amdgcn_rcpf(rs[i] + 1e-8f);
       if (LP > 1) {
         // The LP partial sums meet through the wave's own table: lane `part` > 0 parks its o in the q slot
-        // of the pair's record `part` (a query of lane 0, read into qv long ago: LDS operations of a wave
+        // of the pair's record `part` (read into its owner's qv long ago: LDS operations of a wave
         // complete in issue order), lane 0 adds them in a fixed order. Cross-lane forms measured WRONG
         // here on ROCm 7.2 / gfx950: an update_dpp loop was miscompiled (two DPP instructions for four
         // components) and __shfl_xor (ds_bpermute) returned stale values in ~1e-4 of the pairs with
         // several workgroups per CU.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (part > 0) *reinterpret_cast<vec*>(base + part * kRec) = o;
+        if (part > 0) HeadVec<DK>::store(base + part * kRec, GS, o);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int j = 1; j < LP; ++j) o += *reinterpret_cast<const vec*>(base + j * kRec);   // meaningful on lane 0
+        for (int j = 1; j < LP; ++j) o += HeadVec<DK>::load(base + j * kRec, GS);   // meaningful on lane 0
       }
       const int64_t node = node0 + nb;
-      if (part == 0 && node < n) *reinterpret_cast<vec*>(out + node * ld_out + 16 * wave + hl * DK) = o * inv_t;
+      if (part == 0 && node < n) {
+        const vec ov = o * inv_t;
+        float* dst = out + node * ld_out + cbase + hl * DK;
+        if constexpr (DK == 8) {
+          *reinterpret_cast<float4*>(dst) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(ov[4], ov[5], ov[6], ov[7]);
+        } else {
+          *reinterpret_cast<vec*>(dst) = ov;
+        }
+      }
     }
     // the next tile's products overwrite the table only after its own barriers; its fill overwrites
     // the y images, which every wave finished reading before the barrier above
@@ -307,7 +343,7 @@ __global__ __launch_bounds__(64 * (D / 16), 2) void ln_mhsa_split_kernel(
 namespace sagnn {
 
 bool mhsa_split_supported(int d, int t, int heads) {
-  if (heads != 16 || !(d == 32 || d == 64)) return false;
+  if (heads != 16 || !(d == 32 || d == 64 || d == 128)) return false;
   return (t >= 1 && t <= 6) || t == 8 || t == 12 || t == 16;
 }
 
@@ -315,17 +351,20 @@ template <int D, int T>
 static int launch_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, const float* gamma, const float* beta,
                         float eps, int apply_ln, const float* Wq, const float* bq, const float* Wk, const float* bk,
                         const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s) {
-  constexpr int NW = D / 16, NB = kRows / T;
-  constexpr int LP = lanes_per_pair(T);
+  constexpr int NW = D >= 64 ? 4 : D / 16, NB = kRows / T;
+  constexpr int LP = lanes_per_pair(T, D);
   constexpr int GS = kRows * kRec + NB * pad_node(T) + pad_group(T);
   const size_t lds = (size_t)3 * kRows * D * 2 + (size_t)NW * 4 * GS + (size_t)(kRows + NB) * sizeof(float2);
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&ln_mhsa_split_kernel<D, T, LP>), lds)) return rc;
-  const int per_cu = D == 64 ? 2 : 4;             // ~76 KB / ~38 KB of LDS and <= 256 registers: two waves per SIMD
+  // d = 64 / 32: ~76 KB / ~38 KB of LDS and <= 256 registers -> two waves per SIMD; d = 128: ~98 KB, one workgroup
+  // per CU for each of the two column halves
+  const int per_cu = D == 128 ? 1 : D == 64 ? 2 : 4;
+  constexpr int CB = D == 128 ? 2 : 1;
   const int64_t n_tiles = (n + NB - 1) / NB;
-  const int64_t want = (int64_t)cu_count_current() * per_cu;
-  const int64_t blocks = n_tiles < want ? n_tiles : want;
+  const int64_t want = (int64_t)cu_count_current() * per_cu / CB;
+  const int64_t blocks = n_tiles < want ? n_tiles : (want > 0 ? want : 1);
   ProfileScope prof(kProfMhsa, s, n, T);
-  hipLaunchKernelGGL((ln_mhsa_split_kernel<D, T, LP>), dim3((unsigned)blocks), dim3(64 * NW), lds, s, x, ld_n, ld_t, n,
+  hipLaunchKernelGGL((ln_mhsa_split_kernel<D, T, LP>), dim3((unsigned)blocks, CB), dim3(64 * NW), lds, s, x, ld_n, ld_t, n,
                      gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, n_tiles);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
@@ -350,6 +389,7 @@ int ln_mhsa_mean_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, in
                        const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
                        float* out, int64_t ld_out, hipStream_t s) {
   if (!mhsa_split_supported(d, t, heads)) return fail(SAGNN_ERR_DIM, "split attention: unsupported d/t/heads");
+  if (d == 128) return dispatch_t<128>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
   if (d == 64) return dispatch_t<64>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
   return dispatch_t<32>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
 }

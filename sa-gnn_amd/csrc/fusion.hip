@@ -408,6 +408,13 @@ extern "C" int sagnn_layernorm_td_f32(const float* x, int64_t ld_n, int64_t ld_t
   return SAGNN_OK;
 }
 
+// layer norm + Q|K|V + attention + mean in ONE kernel: the f32-MFMA kernel (d = 32 / 64) or the split-bf16 one
+// (d = 32 / 64 / 128, 16 heads, specialised interval counts)
+static bool fused_attention(int d, int t, int heads) {
+  if (sagnn::force_valu()) return false;
+  return sagnn::mhsa_mfma_supported(d, t, heads) || (sagnn::mhsa_split_supported(d, t, heads) && !sagnn::force_f32_mfma());
+}
+
 extern "C" int sagnn_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
                                    const float* Wq, const float* bq, const float* Wk,
                                    const float* bk, const float* Wv, const float* bv, float* out,
@@ -420,7 +427,7 @@ extern "C" int sagnn_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t ld_t, i
   if (ld_out < d) return sagnn::fail(SAGNN_ERR_ARG, "ld_out smaller than d");
   if (n == 0) return SAGNN_OK;
   const bool vec_ok = sagnn::aligned16(x) && (ld_n & 3) == 0 && (ld_t & 3) == 0;
-  if (sagnn::mhsa_mfma_supported(d, t, heads) && vec_ok && !sagnn::force_valu())
+  if (fused_attention(d, t, heads) && vec_ok)
     return sagnn::ln_mhsa_mean_mfma(x, ld_n, ld_t, n, t, d, heads, nullptr, nullptr, 0.f, 0, Wq, bq, Wk,
                                     bk, Wv, bv, out, ld_out, static_cast<hipStream_t>(stream));
   return sagnn::mhsa_mean_valu(x, ld_n, ld_t, n, t, d, heads, Wq, bq, Wk, bk, Wv, bv, out, ld_out,
@@ -432,7 +439,7 @@ static bool use_wide(int d) { return !sagnn::lstm_mfma_supported(d) && sagnn::wi
 extern "C" size_t sagnn_interval_fusion_workspace_bytes(int64_t n, int t, int d) {
   if (n <= 0 || t <= 0 || d <= 0) return 0;
   size_t bytes = (size_t)n * (size_t)t * (size_t)d * sizeof(float);  // h, normalised in place
-  if (use_wide(d)) bytes += sagnn_mhsa_wide_workspace_bytes(n, t, d);  // Q|K|V of the wide attention
+  if (use_wide(d)) bytes += sagnn_mhsa_wide_workspace_bytes(n, t, d);  // Q|K|V of the wide attention (when it is taken)
   return bytes;
 }
 
@@ -454,7 +461,7 @@ extern "C" int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t l
   if (!ln_gamma || !ln_beta || !Wq || !bq || !Wk || !bk || !Wv || !bv || !out)
     return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
   if (n == 0) return SAGNN_OK;
-  if (use_wide(d)) {  // d = 96, 128, ...: VALU LSTM, MFMA products + per-node kernel for the attention
+  if (use_wide(d) && !fused_attention(d, t, heads)) {  // d = 96, 160, ...: MFMA products + per-node kernel for the attention
     float* scratch = h + n * ldw;
     const size_t sbytes = workspace_bytes - (size_t)n * ldw * sizeof(float);
     if (int rc = sagnn_lstm_fwd_f32(x, ld_n, ld_t, n, t, d, lstm_W, lstm_b, forget_bias, nullptr, h, ldw, stream)) return rc;
@@ -464,7 +471,7 @@ extern "C" int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t l
   if (int rc = sagnn_lstm_fwd_f32(x, ld_n, ld_t, n, t, d, lstm_W, lstm_b, forget_bias, nullptr, h, ldw, stream)) return rc;
   // layer norm rides on the attention kernel's A operand when the matrix-core path applies:
   // h is read once and never rewritten
-  if (sagnn::mhsa_mfma_supported(d, t, heads) && !sagnn::force_valu())
+  if (fused_attention(d, t, heads))
     return sagnn::ln_mhsa_mean_mfma(h, ldw, d, n, t, d, heads, ln_gamma, ln_beta, ln_eps, 1, Wq, bq, Wk, bk,
                                     Wv, bv, out, ld_out, static_cast<hipStream_t>(stream));
   if (int rc = sagnn_layernorm_td_f32(h, ldw, d, n, t, d, ln_gamma, ln_beta, ln_eps, h, ldw, stream)) return rc;
@@ -476,7 +483,7 @@ extern "C" int sagnn_interval_fusion_f32(const float* x, int64_t ld_n, int64_t l
 // forward runs the LSTM separately (it stores gates / cell) and comes here with the emitted h.
 extern "C" size_t sagnn_ln_mhsa_mean_workspace_bytes(int64_t n, int t, int d, int heads) {
   if (n <= 0 || t <= 0 || d <= 0) return 0;
-  if (sagnn::mhsa_mfma_supported(d, t, heads) && !sagnn::force_valu()) return 0;  // normalised in registers
+  if (fused_attention(d, t, heads)) return 0;  // normalised on the way into the product
   size_t bytes = (size_t)n * (size_t)t * (size_t)d * sizeof(float);
   if (use_wide(d)) bytes += sagnn_mhsa_wide_workspace_bytes(n, t, d);
   return bytes;
@@ -495,7 +502,7 @@ extern "C" int sagnn_ln_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t ld_t
   if (ld_out < d) return sagnn::fail(SAGNN_ERR_ARG, "ld_out smaller than d");
   if (n == 0) return SAGNN_OK;
   const bool vec_ok = sagnn::aligned16(x) && (ld_n & 3) == 0 && (ld_t & 3) == 0;
-  if (sagnn::mhsa_mfma_supported(d, t, heads) && vec_ok && !sagnn::force_valu())
+  if (fused_attention(d, t, heads) && vec_ok)
     return sagnn::ln_mhsa_mean_mfma(x, ld_n, ld_t, n, t, d, heads, ln_gamma, ln_beta, ln_eps, 1, Wq, bq, Wk, bk,
                                     Wv, bv, out, ld_out, static_cast<hipStream_t>(stream));
   const size_t ybytes = (size_t)n * t * d * sizeof(float);

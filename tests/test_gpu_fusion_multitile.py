@@ -17,7 +17,9 @@ RTOL, ATOL = 1e-4, 2e-5
 
 # (d, t, n): 100,003 rows = 782 LSTM tiles (3-4 per block, 35 rows in the last); 70,001 at t = 16
 # = 8,751 attention tiles (34 per block, one node in the last)
-CASES = [(64, 2, 100_003), (64, 3, 100_003), (64, 16, 70_001), (32, 2, 100_003), (32, 16, 70_001), (32, 3, 131_077)]
+CASES = [(64, 2, 100_003), (64, 3, 100_003), (64, 16, 70_001), (32, 2, 100_003), (32, 16, 70_001), (32, 3, 131_077),
+         # d = 128 (config 3): one LSTM launch per step over (row tiles) x (4 hidden slices), attention over two column halves
+         (128, 6, 70_001), (128, 3, 50_003)]
 
 
 def _params(d, rng, dev):
@@ -124,3 +126,35 @@ def test_attn_bwd_front_many_tiles_per_block(dev, d, t, n):
     want = qkv.grad.numpy().reshape(n * t, 3 * d)
     err = np.abs(dqkv.cpu().numpy() - want)
     assert (err <= 1e-4 * np.abs(want) + 2e-5 * np.abs(want).max()).all(), f"dqkv worst {err.max():.3e}"
+
+
+@pytest.mark.parametrize("d,t,n", [(64, 3, 20_011), (32, 16, 9_001), (128, 6, 10_007)])
+def test_split_bf16_engine_matches_f32_mfma_engine(dev, d, t, n, monkeypatch):
+    """The fusion GEMMs run on the bf16 matrix cores over EXACTLY split fp32 operands (x = x1 + x2 + x3, six piece
+    products). That is fp32 arithmetic, not a bf16 GEMM: against the round-1 engine (v_mfma_f32_32x32x2_f32, an fmaf
+    chain; SAGNN_GEMM=f32; at d = 128 the VALU LSTM + f32-MFMA dense products) the outputs differ by a few 1e-7 on h
+    and 1e-6 on the fused rows, and both are equally far from the float64 result."""
+    from sa_gnn_amd import ops
+    rng = np.random.default_rng(d + t)
+    x = rng.standard_normal((n, t, d)).astype(np.float32)
+    p, pd = _params(d, rng, dev)
+    xd = torch.from_numpy(x).to(dev)
+    outs = {}
+    for mode in ("split", "f32"):
+        if mode == "f32":
+            monkeypatch.setenv("SAGNN_GEMM", "f32")
+        else:
+            monkeypatch.delenv("SAGNN_GEMM", raising=False)
+        h = ops.lstm_fwd(xd, pd["lstm_W"], pd["lstm_b"], 1.0)
+        f = ops.ln_mhsa_mean(h, pd["ln_gamma"], pd["ln_beta"], pd["Wq"], pd["bq"], pd["Wk"], pd["bk"], pd["Wv"], pd["bv"], 16)
+        outs[mode] = (h.cpu().numpy().astype(np.float64), f.cpu().numpy().astype(np.float64))
+    x64 = x.astype(np.float64)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    h64 = O.basic_lstm(x64, p64["lstm_W"], p64["lstm_b"], 1.0)
+    f64 = O.mhsa(O.layer_norm_td(h64, p64["ln_gamma"], p64["ln_beta"]), p64["Wq"], p64["bq"], p64["Wk"], p64["bk"], p64["Wv"],
+                 p64["bv"], 16).mean(axis=1)
+    assert np.abs(outs["split"][0] - outs["f32"][0]).max() <= 5e-6
+    assert np.abs(outs["split"][1] - outs["f32"][1]).max() <= 2e-5
+    e_split = max(np.abs(outs["split"][0] - h64).max(), np.abs(outs["split"][1] - f64).max())
+    e_f32 = max(np.abs(outs["f32"][0] - h64).max(), np.abs(outs["f32"][1] - f64).max())
+    assert e_split <= 2e-5 and e_split <= 3 * e_f32 + 1e-6, (e_split, e_f32)
