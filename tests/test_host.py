@@ -117,7 +117,8 @@ def test_fusion_argument_errors_without_gpu():
     assert lib.sagnn_attn_bwd_front_f32(None, 0, 0, 4, 2, 64, 16, None, None, 1e-12, 1, None, None, None, None, None, None,
                                         None, 64, None, None, None) == -1
     assert lib.sagnn_ln_mhsa_mean_workspace_bytes(10, 3, 64, 16) == 0          # normalised in registers
-    assert lib.sagnn_ln_mhsa_mean_workspace_bytes(10, 3, 128, 16) == 10 * 3 * 128 * 4 + 10 * 3 * 3 * 128 * 4
+    assert lib.sagnn_ln_mhsa_mean_workspace_bytes(10, 3, 128, 16) == 0         # d = 128, 16 heads: the split-bf16 fused kernel
+    assert lib.sagnn_ln_mhsa_mean_workspace_bytes(10, 3, 128, 8) == 10 * 3 * 128 * 4 + 10 * 3 * 3 * 128 * 4   # wide path
     assert lib.sagnn_ln_mhsa_mean_f32(None, 0, 0, 4, 2, 64, 16, None, None, 1e-12, None, None, None, None, None, None,
                                       None, 64, None, 0, None) == -1
 
