@@ -68,7 +68,8 @@ def parse():
                         "Infinity-Cache-resident hot rows, a plain HBM gather)")
     p.add_argument("--stages", default="full", choices=["full", "spmm", "train"],
                    help="spmm = time the SpMM stack alone; train = forward + backward + Adam of the hot "
-                        "path (N = 1; loss = sum of the fused embeddings) — not the headline metric")
+                        "path (loss = sum of the fused embeddings; N > 1: reverse all-to-all + reduce-scatter) — "
+                        "not the headline metric")
     p.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-breakdown", action="store_true",
@@ -135,7 +136,7 @@ def main():
     if split and a.exchange != "alltoall":
         raise SystemExit("T < world runs the all-to-all exchange only")
     if split and a.stages == "train":
-        raise SystemExit("--stages train is a single-GPU measurement")
+        raise SystemExit("--stages train needs whole intervals per rank (T >= world)")
     tuning = tuple(int(v) for v in a.tuning.split(",")) if a.tuning else None
     group = None
     if split:
@@ -251,30 +252,50 @@ def main():
         state["final"] = [fin().to(dev) for _, fin in pending]
 
     if a.stages == "train":
-        if world != 1:
-            raise SystemExit("--stages train is a single-GPU measurement")
+        # forward + backward + Adam of the hot path. N > 1: the exchange and the gather carry their adjoints
+        # (reverse all-to-all, reduce-scatter: parallel.ExchangeRowsFn / GatherFusedFn), every rank's loss is the
+        # sum of ITS rows of the fused embeddings (the total is the N = 1 loss), the replicated fusion weights'
+        # gradients are all-reduced, each rank steps its own intervals' embeddings.
+        if split or t_loc == 0:
+            raise SystemExit("--stages train needs at least one whole interval per rank")
         from sa_gnn_amd import autograd as ag
-        leaves = {"uEmbed": torch.stack([e[0] for e in emb]).requires_grad_(True),      # [T, U, d] / [T, I, d] as the model holds them
+        from sa_gnn_amd.parallel import allreduce_grads, exchange_rows, gather_rows
+        leaves = {"uEmbed": torch.stack([e[0] for e in emb]).requires_grad_(True),      # [T_local, U, d] / [T_local, I, d]
                   "iEmbed": torch.stack([e[1] for e in emb]).requires_grad_(True)}
         emb.clear()
         torch.cuda.empty_cache()
+        shared = []
         for tag, p in (("U", prm[0]), ("I", prm[1])):
             for k, v in p.items():
                 if tag == "I" and k in ("lstm_W", "lstm_b"):
                     continue                              # the cell is shared: one leaf
                 leaves[f"{tag}.{k}"] = v.requires_grad_(True)
+                shared.append(v)
         opt = ops.Adam(leaves, lr=1e-3, decay=0.96, decay_step=19, reg=1e-2, reg_names=["uEmbed", "iEmbed"])
         pl_u, pl_i = [pp[0] for pp in plans], [pp[1] for pp in plans]
 
         def step():                                       # noqa: F811  (training step replaces the forward step)
             for v in leaves.values():
                 v.grad = None
-            us, its = ag.gnn_stack(leaves["uEmbed"], leaves["iEmbed"], pl_u, pl_i, L, 0.5)      # [T, N, d] slabs, no stack copy
-            fu = ag.interval_fusion(us.permute(1, 0, 2), prm[0], heads)
-            fi = ag.interval_fusion(its.permute(1, 0, 2), prm[1], heads)
-            (fu.sum() + fi.sum()).backward()
+            us, its = ag.gnn_stack(leaves["uEmbed"], leaves["iEmbed"], pl_u, pl_i, L, 0.5)      # [T_local, N, d] slabs, no stack copy
+            finals, loss = [], 0.0
+            for xs, n_rows, p in ((us, U, prm[0]), (its, I, prm[1])):
+                if world > 1:
+                    xs = exchange_rows(xs.to(comm_dev), sh, n_rows).to(dev)                        # [T, rows_local, d]
+                f_loc = ag.interval_fusion(xs.permute(1, 0, 2), p, heads)
+                loss = loss + f_loc.sum()                                                          # this rank's rows
+                finals.append(gather_rows(f_loc.to(comm_dev), sh, n_rows).to(dev) if world > 1 else f_loc)
+            loss.backward()
+            if world > 1:
+                if rehearsal:
+                    for v in shared:                      # gloo all-reduces host copies
+                        gcpu = v.grad.cpu()
+                        dist.all_reduce(gcpu)
+                        v.grad.copy_(gcpu)
+                else:
+                    allreduce_grads(shared)
             opt.step({k: v.grad for k, v in leaves.items()})
-            state["final"] = [fu.detach(), fi.detach()]
+            state["final"] = [f.detach() for f in finals]
 
     def sync():
         torch.cuda.synchronize()

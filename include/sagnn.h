@@ -237,6 +237,15 @@ int sagnn_gnn_interval_bwd_f32(const sagnn_spmm_plan* plan_user, const sagnn_spm
  * sagnn_interval_fusion_f32 — the three stages back to back on `stream` with the LSTM
  *   output kept in a caller-provided workspace (sagnn_interval_fusion_workspace_bytes) and
  *   normalised in place; only out [n, d] is a result.
+ *
+ * ARITHMETIC of the GEMM-shaped stages (the gate product [x_t | h] W and the three dense layers)
+ *   for d in {32, 64, 128}, 16 heads: fp32 in, fp32 out, evaluated on the bf16 matrix cores over
+ *   EXACTLY split operands — every fp32 value is cut into three bf16 pieces (x = x1 + x2 + x3 by
+ *   masking, no rounding), a product is the sum of its six largest piece products (bf16 x bf16 is
+ *   exact in fp32), accumulated in fp32; what is dropped is < 2^-20 |a b|. The result is as close
+ *   to the float64 product as an fp32 fmaf chain, not bit-identical to one. Environment:
+ *   SAGNN_GEMM=f32 selects v_mfma_f32_32x32x2_f32 kernels (an fmaf chain bit for bit; d = 32 / 64),
+ *   SAGNN_FUSION=valu the VALU formulations. Results are deterministic run to run in every mode.
  * -------------------------------------------------------------------------------- */
 int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
                        const float* b, float forget_bias, const float* drop_scale, float* h,

@@ -418,3 +418,100 @@ def gather_fused(final_local: torch.Tensor, sh: IntervalSharding, n_rows: int, g
     if async_op:
         return out, finish
     return finish()
+
+
+# ----------------------------------------------------------------------------------------------
+# Backward of the exchange: what tf.gradients would add if the reference were sharded this way.
+# all-gather  <->  reduce-scatter;  all-to-all into row shards  <->  the reverse all-to-all.
+# ----------------------------------------------------------------------------------------------
+
+
+def _reduce_scatter_rows(g: torch.Tensor, sh: IntervalSharding, n_rows: int, group=None) -> torch.Tensor:
+    """sum over ranks of g [N, d], each rank keeping its row shard [rows_local, d]."""
+    lo, hi = sh.row_range(n_rows)
+    if sh.world == 1:
+        return g[lo:hi]
+    g = g.contiguous()
+    if dist.get_backend(group) == "gloo":          # gloo has no reduce-scatter: all-reduce, keep the shard
+        full = g.clone()
+        dist.all_reduce(full, group=group)
+        return full[lo:hi].contiguous()
+    d = g.shape[-1]
+    bounds = sh.row_bounds(n_rows)
+    if n_rows % sh.world == 0:
+        out = g.new_empty((hi - lo, d))
+        dist.reduce_scatter_tensor(out, g, group=group)
+        return out
+    rmax = bounds[1] - bounds[0]                    # pad every shard to the largest one
+    padded = g.new_zeros((sh.world * rmax, d))
+    for r in range(sh.world):
+        padded[r * rmax: r * rmax + bounds[r + 1] - bounds[r]] = g[bounds[r]:bounds[r + 1]]
+    out = g.new_empty((rmax, d))
+    dist.reduce_scatter_tensor(out, padded, group=group)
+    return out[: hi - lo].contiguous()
+
+
+class GatherFusedFn(torch.autograd.Function):
+    """gather_fused with its adjoint: forward all-gathers the fused rows [rows_local, d] -> [N, d]; backward
+    reduce-scatters dL/dF (every rank may hold a different contribution: its own batch of users) back to the
+    row shards — the 'matching reduce-scatter' of SURVEY.md §8(e)."""
+
+    @staticmethod
+    def forward(ctx, f_local, sh, n_rows, group):
+        ctx.sh, ctx.n_rows, ctx.group = sh, n_rows, group
+        return gather_fused(f_local.detach(), sh, n_rows, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _reduce_scatter_rows(g, ctx.sh, ctx.n_rows, ctx.group), None, None, None
+
+
+class ExchangeRowsFn(torch.autograd.Function):
+    """exchange_to_row_shards(mode="alltoall") with its adjoint: forward [T_local, N, d] -> x [T, rows_local, d];
+    backward sends every interval's gradient rows back to the interval's owner (the same all-to-all with send and
+    receive swapped), which reassembles dL/d(out_k) [N, d] for its local intervals."""
+
+    @staticmethod
+    def forward(ctx, local_out, sh, n_rows, group):
+        if isinstance(sh, SplitIntervalSharding):
+            raise NotImplementedError("backward of the row-split exchange (T < world) is not built")
+        ctx.sh, ctx.n_rows, ctx.group, ctx.t_loc = sh, n_rows, group, local_out.shape[0]
+        return exchange_to_row_shards(local_out.detach().contiguous(), sh, n_rows, group, mode="alltoall")
+
+    @staticmethod
+    def backward(ctx, g):
+        sh, n_rows = ctx.sh, ctx.n_rows
+        d = g.shape[-1]
+        if sh.world == 1:
+            return g, None, None, None
+        g = g.contiguous()
+        bounds = sh.row_bounds(n_rows)
+        rows_local = bounds[sh.rank + 1] - bounds[sh.rank]
+        d_local = g.new_empty((ctx.t_loc, n_rows, d))
+        shard_sizes = [bounds[r + 1] - bounds[r] for r in range(sh.world)]
+        for j in range(sh.rounds):
+            have = j < ctx.t_loc
+            cnt = min(sh.world, sh.T - j * sh.world)              # owners that hold a j-th interval
+            send = g[j * sh.world: j * sh.world + cnt].reshape(cnt * rows_local, d)
+            recv = d_local[j] if have else g.new_empty((0, d))
+            dist.all_to_all_single(recv, send, output_split_sizes=shard_sizes if have else [0] * sh.world,
+                                   input_split_sizes=[rows_local if s < cnt else 0 for s in range(sh.world)],
+                                   group=ctx.group)
+        return d_local, None, None, None
+
+
+def exchange_rows(local_out: torch.Tensor, sh: IntervalSharding, n_rows: int, group=None) -> torch.Tensor:
+    return ExchangeRowsFn.apply(local_out, sh, n_rows, group)
+
+
+def gather_rows(f_local: torch.Tensor, sh: IntervalSharding, n_rows: int, group=None) -> torch.Tensor:
+    return GatherFusedFn.apply(f_local, sh, n_rows, group)
+
+
+def allreduce_grads(tensors, group=None):
+    """Sums the gradients of replicated parameters (the fusion weights: every rank saw only its rows)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in tensors:
+        if t.grad is not None:
+            dist.all_reduce(t.grad, group=group)

@@ -98,3 +98,16 @@ def test_rccl_two_gpus_smoke():
                 "--master-addr", "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "2"] + common)
     assert one["final_abs_mean"] == two["final_abs_mean"]
     assert one["final_position_checksum"] == two["final_position_checksum"]
+
+
+def test_two_rank_training_step_matches_single_process():
+    """Forward + backward + Adam at N = 2 (gloo rehearsal on one GPU): the exchange and the gather carry their adjoints
+    (reverse all-to-all, reduce-scatter), the fusion weights' gradients are all-reduced. After two steps the fused
+    embeddings of both runs agree (weight-gradient sums use float atomics: not bit for bit)."""
+    common = ["--stages", "train", "--steps", "2", "--warmup", "0", "--scale", "0.002", "--no-cpu-baseline", "--intervals", "4"]
+    one = _run([sys.executable, "bench.py"] + common)
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                "--master-addr", "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "2",
+                "--dist-backend", "gloo"] + common)
+    for a_, b_ in zip(one["final_abs_mean"] + one["final_position_checksum"], two["final_abs_mean"] + two["final_position_checksum"]):
+        assert abs(a_ - b_) <= 2e-5 * abs(a_), (one["final_abs_mean"], two["final_abs_mean"])

@@ -237,3 +237,59 @@ def test_split_sharding_maps():
     assert SplitIntervalSharding(3, 8, 0, None).group_size == [3, 3, 2]
     with pytest.raises(ValueError):
         SplitIntervalSharding(8, 8, 0)
+
+
+# ---- backward of the exchange: reduce-scatter / reverse all-to-all ------------------------------------
+def _bwd_worker(rank, world, port, T, q):
+    from sa_gnn_amd.parallel import allreduce_grads, exchange_rows, gather_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        U, d = 23, 16
+        rng = np.random.default_rng(11)
+        leaves_all = rng.standard_normal((T, U, d))                    # one "interval output" per interval
+        wts = rng.standard_normal((world, U, d))                       # rank r's loss weights (its own batch)
+        p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in O.init_fusion_params(d, rng).items()}
+        sh = IntervalSharding(T, world, rank)
+        mine = sh.local_intervals
+        leaf = torch.tensor(leaves_all[mine] if mine else np.zeros((0, U, d)), dtype=torch.float64, requires_grad=True)
+        x = exchange_rows(torch.tanh(leaf), sh, U)                     # [T, rows_local, d]
+        f_loc = O.torch_interval_fusion(x.permute(1, 0, 2), p, 4)      # [rows_local, d]
+        F = gather_rows(f_loc, sh, U)                                  # [U, d] everywhere
+        loss = (F * torch.tensor(wts[rank])).sum()                     # every rank a DIFFERENT loss term
+        loss.backward()
+        allreduce_grads(p.values())
+        q.put((rank, mine, leaf.grad.numpy(), {k: v.grad.numpy() for k, v in p.items()}, float(loss)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T", [(2, 4), (3, 7), (2, 3), (3, 2)])
+def test_distributed_backward_matches_single_process(world, T):
+    """Gradients through gather (adjoint: reduce-scatter) and exchange (adjoint: reverse all-to-all), with a
+    different loss term on every rank, against single-process float64 autograd of the summed loss."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bwd_worker, args=(r, world, port, T, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p_ in procs:
+        p_.join(60)
+        assert p_.exitcode == 0
+    U, d = 23, 16
+    rng = np.random.default_rng(11)
+    leaves_all = rng.standard_normal((T, U, d))
+    wts = rng.standard_normal((world, U, d))
+    p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in O.init_fusion_params(d, rng).items()}
+    leaf = torch.tensor(leaves_all, dtype=torch.float64, requires_grad=True)
+    F = O.torch_interval_fusion(torch.tanh(leaf).permute(1, 0, 2), p, 4)
+    (F * torch.tensor(wts.sum(0))).sum().backward()
+    assert abs(sum(r[4] for r in res) - float((F * torch.tensor(wts.sum(0))).sum())) < 1e-9
+    for rank, mine, g_leaf, g_p, _ in res:
+        if mine:
+            np.testing.assert_allclose(g_leaf, leaf.grad.numpy()[mine], rtol=1e-9, atol=1e-12)
+        for k in p:
+            np.testing.assert_allclose(g_p[k], p[k].grad.numpy(), rtol=1e-9, atol=1e-11)
