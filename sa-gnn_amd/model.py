@@ -215,57 +215,91 @@ class Recommender:
         as_i32 = lambda v: torch.as_tensor(np.asarray(v, dtype=np.int32), device=self.device)
         return ops.pair_score(fu, fi, as_i32(uids), as_i32(iids), S=att, A=fi, locs=as_i32(uLocs_seq), leaky=leaky)
 
+    def _test_candidates(self):
+        """test_dict (1-indexed user -> 1-indexed candidate items, preprocess_to_sequence.ipynb cell 11) as one int32
+        matrix [test users, testSize - 1] of 0-indexed negatives + the row of every user in it; built once (the
+        reference re-reads the dict per user and batch: 25 ms of list -> array conversions per 512-user batch)."""
+        cached = getattr(self, "_tst_cache", None)
+        if cached is None or cached[2] is not self.handler.test_dict or cached[3] != args.testSize:
+            users = np.asarray(self.handler.tstUsrs, dtype=np.int64)
+            row_of = np.full(args.user, -1, dtype=np.int64)
+            row_of[users] = np.arange(len(users))
+            k = args.testSize - 1
+            neg = np.empty((len(users), k), dtype=np.int32)
+            for r, u in enumerate(users):
+                cand = self.handler.test_dict[int(u) + 1][:k]
+                if len(cand) != k:
+                    raise ValueError(f"test_dict[{int(u) + 1}] holds {len(cand)} candidates, testSize - 1 = {k} needed")
+                neg[r] = cand
+            neg -= 1
+            cached = self._tst_cache = (neg, row_of, self.handler.test_dict, args.testSize)
+        return cached[0], cached[1]
+
     def sampleTestBatch(self, batIds, labelMat=None):
         """reference model.py:384-428: args.testSize-1 pre-drawn negatives from test_dict
         (1-indexed user keys and item ids) plus the held-out positive LAST; the user's whole
-        sequence, right-aligned into pos_length slots."""
-        batch = len(batIds)
+        sequence, right-aligned into pos_length slots. Vectorised over the batch (users outside
+        handler.tstUsrs take the reference's per-user path)."""
+        batIds = np.asarray(batIds, dtype=np.int64)
+        batch, P = len(batIds), args.pos_length
         temTst = self.handler.tstInt[batIds]
-        tstLocs = []
-        sequence = np.zeros((args.batch, args.pos_length), dtype=np.int64)
-        mask = np.zeros((args.batch, args.pos_length), dtype=np.float32)
+        flat, ptr = self._flat_sequences()
+        start, end = ptr[batIds], ptr[batIds + 1]
         val_list = [None] * args.batch
-        for i in range(batch):
-            u = int(batIds[i])
-            if args.test:
-                posloc = temTst[i]
-                posset = self.handler.sequence[u]
-            else:
-                posloc = self.handler.sequence[u][-1]
-                val_list[i] = posloc
-                posset = self.handler.sequence[u][:-1]
-            neg = np.asarray(self.handler.test_dict[u + 1][:args.testSize - 1], dtype=np.int64) - 1
-            tstLocs.append(np.concatenate((neg, np.array([posloc], dtype=np.int64))))
-            if len(posset) == 0:
-                continue
-            if len(posset) <= args.pos_length:
-                sequence[i, -len(posset):] = posset
-                mask[i, -len(posset):] = 1
-            else:
-                sequence[i] = posset[-args.pos_length:]
-                mask[i] = 1
-        lens = np.fromiter((len(t) for t in tstLocs), dtype=np.int64, count=batch)
-        uLocs = np.repeat(np.asarray(batIds, dtype=np.int64), lens)
-        uLocs_seq = np.repeat(np.arange(batch, dtype=np.int64), lens)
-        iLocs = np.concatenate(tstLocs) if batch else np.zeros(0, dtype=np.int64)
+        if args.test:
+            posloc = np.array([(-1 if t is None else t) for t in temTst], dtype=np.int64)
+            seq_end = end                                         # posset = the whole sequence
+        else:
+            posloc = flat[np.maximum(end - 1, start)]             # last item held out for validation
+            seq_end = np.maximum(end - 1, start)
+            for i in range(batch):
+                val_list[i] = int(posloc[i])
+        neg_all, row_of = self._test_candidates()
+        rows = row_of[batIds]
+        if (rows < 0).any():                                      # not a test user: fall back to the dict
+            neg = np.stack([np.asarray(self.handler.test_dict[int(u) + 1][:args.testSize - 1], dtype=np.int64) - 1
+                            for u in batIds])
+        else:
+            neg = neg_all[rows].astype(np.int64)
+        locs = np.concatenate([neg, posloc[:, None]], axis=1)     # [batch, testSize], positive LAST
+        tstLocs = list(locs)
+        # sequences: the last min(len, P) items, right-aligned
+        n_pos = seq_end - start
+        k = np.minimum(n_pos, P)
+        sequence = np.zeros((args.batch, P), dtype=np.int64)
+        mask = np.zeros((args.batch, P), dtype=np.float32)
+        rws = np.repeat(np.arange(batch, dtype=np.int64), k)
+        within = np.arange(int(k.sum()), dtype=np.int64) - np.repeat(np.cumsum(k) - k, k)
+        sequence[rws, P - k[rws] + within] = flat[seq_end[rws] - k[rws] + within]
+        mask[rws, P - k[rws] + within] = 1
+        C = locs.shape[1]
+        uLocs = np.repeat(batIds, C)
+        uLocs_seq = np.repeat(np.arange(batch, dtype=np.int64), C)
+        iLocs = locs.reshape(-1)
         return uLocs, iLocs, temTst, tstLocs, sequence, mask, uLocs_seq, val_list
 
     @staticmethod
     def calcRes(preds, temTst, tstLocs, shoot=None):
-        """reference model.py:484-510 vectorised: a stable descending sort keeps the candidate
-        order among ties and the positive is the last candidate, so it loses them."""
+        """reference model.py:484-510 without the sort. The reference ranks the candidates by a stable
+        descending sort (ties keep candidate order; the positive is the LAST candidate, so it loses them) and
+        takes `list.index(target)` in the top k, i.e. the best-ranked copy of the target item (a pre-drawn
+        negative may be the same item). That rank is  #(pred > p) + #(earlier candidates with pred == p)  for
+        p = the copies' highest score, j = its first copy — counted directly, O(candidates) per user instead of
+        an argsort of [batch, testSize] (15 ms per batch: 80 % of a test epoch)."""
         shoot = args.shoot if shoot is None else shoot
         preds = np.asarray(preds)
         locs = np.stack([np.asarray(t) for t in tstLocs])                      # [B, C]
-        order = np.argsort(-preds, axis=1, kind="stable")
-        ranked = np.take_along_axis(locs, order, axis=1)
-        target = np.asarray([(-1 if t is None else t) for t in temTst[:len(locs)]])[:, None]
+        B, C = locs.shape
+        target = np.asarray([(-1 if t is None else t) for t in temTst[:B]])[:, None]
+        copies = locs == target
+        has = copies.any(1)
+        p_best = np.where(copies, preds, -np.inf).max(1)                       # highest score among the copies
+        first = (copies & (preds == p_best[:, None])).argmax(1)                 # its first candidate index
+        ahead = (preds > p_best[:, None]).sum(1) + ((preds == p_best[:, None]) & (np.arange(C)[None, :] < first[:, None])).sum(1)
         res = []
         for k in (shoot, 5, 20):
-            hitpos = ranked[:, :k] == target                                     # first match = list.index
-            hit = hitpos.any(1)
-            first = hitpos.argmax(1)
-            res += [float(hit.sum()), float((1.0 / np.log2(first[hit] + 2)).sum())]
+            hit = has & (ahead < k)
+            res += [float(hit.sum()), float((1.0 / np.log2(ahead[hit] + 2)).sum())]
         return tuple(res)
 
     def testEpoch(self):
@@ -331,10 +365,10 @@ class Recommender:
         # ---- SSL (model.py:174-205)
         ssl = torch.zeros(1, dtype=torch.float32, device=self.device)
         for k in range(T):
+            if len(batch["suids"][k]) < 2:
+                continue
             su, si = self._i32(batch["suids"][k]), self._i32(batch["siids"][k])
             ns = su.numel() // 2
-            if ns == 0:
-                continue
             w = ag.MetaWeightFn.apply(fu, uv[k], su, self.meta2_W, self.meta2_b, self.meta3_W, self.meta3_b, leaky)
             s_final = ag.ProdLeakySumFn.apply(fu.detach(), fi.detach(), su, si, leaky)      # stop_gradient
             p1 = ag.ProdLeakySumFn.apply(uv[k], iv[k], su, si, leaky)
@@ -343,21 +377,24 @@ class Recommender:
 
     def _masked_sum_plans_t(self, sequence, mask):
         """Transposed per-batch CSRs (rows = items / positions, columns = batch slots) for the
-        backward of the masked sums."""
+        backward of the masked sums. scipy's CSR -> CSC conversion is a counting sort that keeps
+        duplicated entries (an item twice in a sequence counts twice), 4x cheaper than an argsort."""
+        import scipy.sparse as sp
         sequence = np.asarray(sequence, dtype=np.int64)
         keep = np.asarray(mask) != 0
         B, L = keep.shape
-        slots = np.broadcast_to(np.arange(B, dtype=np.int32)[:, None], (B, L))[keep]
+        rowptr = np.zeros(B + 1, dtype=np.int32)
+        np.cumsum(keep.sum(1), out=rowptr[1:])
+        nnz = int(rowptr[-1])
         out = []
-        for rows, n_rows in ((sequence[keep], args.item), (np.broadcast_to(np.arange(L), (B, L))[keep], L)):
-            order = np.argsort(rows, kind="stable")
-            rowptr = np.zeros(n_rows + 1, dtype=np.int32)
-            np.cumsum(np.bincount(rows, minlength=n_rows), out=rowptr[1:])
-            out.append(ops.SpmmPlan(rowptr, np.ascontiguousarray(slots[order]), n_rows, B, device=self.device,
+        for cols, n_rows in ((sequence[keep].astype(np.int32), args.item),
+                             (np.broadcast_to(np.arange(L, dtype=np.int32), (B, L))[keep], L)):
+            csc = sp.csr_matrix((np.ones(nnz, dtype=np.int8), cols, rowptr), shape=(B, n_rows)).tocsc()
+            out.append(ops.SpmmPlan(csc.indptr.astype(np.int32), csc.indices.astype(np.int32), n_rows, B, device=self.device,
                                     validate=False))
         return out
 
-    def sampleTrainBatch(self, batIds, labelMat, timeMat=None, train_sample_num=40):
+    def sampleTrainBatch(self, batIds, labelMat, timeMat=None, train_sample_num=40, as_arrays=False):
         """reference model.py:252-302: per user ONE positive (one of the last pred_num+1 items before
         the held-out one, repeated sampNum times) against sampNum uniform negatives the user has
         not interacted with (and != the last item / the test item); the sequence fed to the head
@@ -407,8 +444,10 @@ class Recommender:
         within = np.arange(int(k.sum()), dtype=np.int64) - np.repeat(np.cumsum(k) - k, k)
         sequence[rows, P - k[rows] + within] = flat[start[rows] + m[rows] - k[rows] + within]
         mask[rows, P - k[rows] + within] = 1
-        return (np.concatenate([half_u, half_u]).tolist(), np.concatenate([half_i, negs]).tolist(), sequence, mask,
-                np.concatenate([half_l, half_l]).tolist())
+        uL, iL, uLs = np.concatenate([half_u, half_u]), np.concatenate([half_i, negs]), np.concatenate([half_l, half_l])
+        if as_arrays:      # the epoch loop keeps int32 arrays end to end (the list round trip cost 2 ms per step)
+            return uL.astype(np.int32), iL.astype(np.int32), sequence, mask, uLs.astype(np.int32)
+        return uL.tolist(), iL.tolist(), sequence, mask, uLs.tolist()       # the reference's feed_dict lists
 
     def _flat_sequences(self):
         """handler.sequence (one array per user) as one flat int64 array + offsets, built once."""
@@ -422,7 +461,7 @@ class Recommender:
             cached = self._seq_cache = (flat, ptr, seqs)
         return cached[0], cached[1]
 
-    def sampleSslBatch(self, batIds, labelMat, use_epsilon=True):
+    def sampleSslBatch(self, batIds, labelMat, use_epsilon=True, as_arrays=False):
         """reference model.py:304-339: per interval and user up to sslNum (item, item) pairs drawn
         with replacement from the user's items of that interval, written INTERLEAVED
         (pair j at 2j, 2j+1) — the loss later splits the vector by halves (model.py:192-201).
@@ -436,7 +475,8 @@ class Recommender:
             npair = np.minimum(args.sslNum, deg // 2)                # pairs per user
             total = int(npair.sum())
             if total == 0:
-                uLocs.append([]); iLocs.append([]); uLocs_seq.append([])
+                empty = np.zeros(0, np.int32) if as_arrays else []
+                uLocs.append(empty); iLocs.append(empty); uLocs_seq.append(empty)
                 continue
             slot = np.repeat(np.arange(len(batIds)), npair)          # batch slot of every pair
             base = lab.indptr[:-1][slot]
@@ -444,9 +484,14 @@ class Recommender:
             second = lab.indices[base + (rng.random_sample(total) * deg[slot]).astype(np.int64)]
             its = np.empty(2 * total, dtype=np.int64)
             its[0::2], its[1::2] = first, second
-            uLocs.append(np.repeat(batIds[slot], 2).tolist())
-            iLocs.append(its.tolist())
-            uLocs_seq.append(np.repeat(slot, 2).tolist())
+            if as_arrays:
+                uLocs.append(np.repeat(batIds[slot], 2).astype(np.int32))
+                iLocs.append(its.astype(np.int32))
+                uLocs_seq.append(np.repeat(slot, 2).astype(np.int32))
+            else:
+                uLocs.append(np.repeat(batIds[slot], 2).tolist())
+                iLocs.append(its.tolist())
+                uLocs_seq.append(np.repeat(slot, 2).tolist())
         return uLocs, iLocs, uLocs_seq
 
     def _trainable(self):
@@ -458,12 +503,15 @@ class Recommender:
             self.optimizer = self._make_optimizer()
         sfIds = np.random.permutation(args.user)[:args.trnNum]
         steps = int(np.ceil(len(sfIds) / args.batch))
-        epochLoss = epochPreLoss = 0.0
+        # losses stay on the device until the epoch ends: a float() per step would make the host wait for the
+        # step's kernels before it samples the next batch (host sampling and device work overlap this way)
+        loss_sum = torch.zeros(1, dtype=torch.float32, device=self.device)
+        pre_sum = torch.zeros(1, dtype=torch.float32, device=self.device)
         for i in range(steps):
             batIds = sfIds[i * args.batch:(i + 1) * args.batch]
             uLocs, iLocs, sequence, mask, uLocs_seq = self.sampleTrainBatch(batIds, self.handler.trnMat,
-                                                                            self.handler.timeMat, 40)
-            suLocs, siLocs, _ = self.sampleSslBatch(batIds, self.handler.subMat, False)
+                                                                            self.handler.timeMat, 40, as_arrays=True)
+            suLocs, siLocs, _ = self.sampleSslBatch(batIds, self.handler.subMat, False, as_arrays=True)
             batch = {"uids": uLocs, "iids": iLocs, "uLocs_seq": uLocs_seq, "sequence": sequence, "mask": mask,
                      "suids": suLocs, "siids": siLocs}
             params = self._trainable()
@@ -472,11 +520,10 @@ class Recommender:
             pre, ssl = self.train_loss(batch)
             (pre + args.ssl_reg * ssl).backward()
             with torch.no_grad():
-                reg = float(args.reg * NNs.Regularize()) + float(args.ssl_reg * ssl)
+                pre_sum += pre.detach()
+                loss_sum += pre.detach() + args.reg * NNs.Regularize() + args.ssl_reg * ssl.detach()
             self.optimizer.step({k: p.grad for k, p in params.items()})
-            epochPreLoss += float(pre.detach())
-            epochLoss += float(pre.detach()) + reg
-        return {"Loss": epochLoss / steps, "preLoss": epochPreLoss / steps}
+        return {"Loss": float(loss_sum) / steps, "preLoss": float(pre_sum) / steps}
 
     def _make_optimizer(self):
         return ops.Adam(self._trainable(), lr=args.lr, decay=args.decay, decay_step=args.decay_step,

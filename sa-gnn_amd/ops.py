@@ -14,7 +14,9 @@ SUPPORTED_D = tuple(range(4, 257, 4))
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    # the raw handle of torch's current stream; torch.cuda.current_stream() builds a Stream object per call
+    # (10 us, a few hundred times per training step)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 def _ptr(t: torch.Tensor | None) -> int | None:

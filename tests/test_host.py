@@ -231,3 +231,22 @@ def test_sampler_invariants():
         assert len(su[k]) % 2 == 0 and su[k][0::2] == su[k][1::2]
         for e in range(len(su[k])):
             assert h.subMat[k][su[k][e], si[k][e]] != 0
+
+
+def test_calc_res_counts_match_the_reference_loop_on_ties_and_duplicates():
+    """Recommender.calcRes ranks without sorting (rank = #(pred > p) + #(earlier candidates with pred == p) of the
+    best-ranked copy of the target item). Against the oracle's restatement of the reference's sort + list.index loop
+    (model.py:484-510) on heavily tied scores and candidate lists that repeat item ids (a pre-drawn negative may
+    be the held-out item itself; equal items have equal scores)."""
+    from oracle import selfgnn_oracle as O
+    from sa_gnn_amd.model import Recommender
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        B, C = 13, 29
+        locs = [rng.integers(0, 12, size=C) for _ in range(B)]
+        tem = [int(l[-1]) for l in locs]                                  # the positive is the last candidate
+        preds = np.round(rng.standard_normal((B, C)), 1).astype(np.float32)
+        for b in range(B):
+            for c in range(C):
+                preds[b, c] = preds[b, np.argmax(locs[b] == locs[b][c])]
+        np.testing.assert_allclose(Recommender.calcRes(preds, tem, locs, shoot=10), O.calc_res(preds, tem, locs, shoot=10))
