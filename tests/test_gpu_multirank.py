@@ -56,13 +56,15 @@ def test_three_ranks_round_wise_fusion_matches_single_process():
 
 
 def test_four_ranks_match_single_process():
-    """Four ranks sharing the GPU, eight intervals (two per rank, as the scaling benchmark runs)."""
+    """Four ranks sharing the GPU on the DEFAULT configuration (strong scaling: the 16 intervals of configs[4], four
+    per rank, four exchange rounds, T = 16 fusion) at a reduced scale."""
     common = ["--steps", "1", "--warmup", "1", "--scale", "0.002", "--no-cpu-baseline"]
-    one = _run([sys.executable, "bench.py", "--intervals", "8"] + common)
+    one = _run([sys.executable, "bench.py"] + common)
     four = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
                  "--master-addr", "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "4",
-                 "--dist-backend", "gloo", "--intervals", "8"] + common)
-    assert one["config"]["intervals_total"] == four["config"]["intervals_total"] == 8
+                 "--dist-backend", "gloo"] + common)
+    assert one["scaling"] == four["scaling"] == "strong"
+    assert one["config"]["intervals_total"] == four["config"]["intervals_total"] == 16
     assert one["final_abs_mean"] == four["final_abs_mean"]
     assert one["final_position_checksum"] == four["final_position_checksum"]
 
