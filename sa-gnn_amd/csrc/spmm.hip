@@ -27,6 +27,10 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;              // 4 waves
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kRowsPerWave = 16;         // row block per wavefront (rowptr slice fits one lane each)
+// Dataset-sized graphs (tens of thousands of rows: Gowalla, Amazon, MovieLens) give 16-row blocks only a dozen
+// waves per CU and every launch is a chain of three dependent L2 round trips: below kSmallRows rows a wave takes
+// ONE row per lane group (4 rows at d = 64), four times the waves in flight.
+constexpr int64_t kSmallRows = 262144;
 constexpr int kUnroll = 8;               // gather instructions in flight per wave
 
 struct Epilogue {
@@ -196,7 +200,7 @@ __device__ __forceinline__ float4 wave_row_sum(const int32_t* __restrict__ colid
 
 // One launch covers the long-row chunks (first `chunk_blocks` blocks, heaviest work first)
 // and the row blocks (remaining blocks).
-template <int LPR>
+template <int LPR, int RPW>
 __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
     const float* __restrict__ X, int64_t ldx, int d, int64_t n_rows, int short_t, int long_t,
@@ -219,9 +223,9 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
     return;
   }
 
-  const int64_t row0 = ((int64_t)(blockIdx.x - chunk_blocks) * kWavesPerBlock + wave) * kRowsPerWave;
+  const int64_t row0 = ((int64_t)(blockIdx.x - chunk_blocks) * kWavesPerBlock + wave) * RPW;
   if (row0 >= n_rows) return;
-  const int nr = (int)min((int64_t)kRowsPerWave, n_rows - row0);
+  const int nr = (int)min((int64_t)RPW, n_rows - row0);
   // lane l (l <= nr) holds rowptr[row0 + l]; lanes beyond replicate the last entry (degree 0).
   const int rp = rowptr[row0 + min(lane, nr)];
   // the shuffle must run with every lane active: a lane masked off by the select below would
@@ -238,14 +242,14 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
   int idx_n = -1;
   if (dg_n <= short_t && sub < dg_n) idx_n = ldi_s(colidx + e0_n + sub);
 #pragma unroll 1
-  for (int it = 0; it < kRowsPerWave / G; ++it) {
+  for (int it = 0; it < RPW / G; ++it) {
     const int lr = it * G + grp;
     const int e0 = e0_n;
     const int dg = dg_n;
     int idx = idx_n;
     const bool mine = (lr < nr) && (dg <= short_t);
     const int my_deg = mine ? dg : 0;
-    if (it + 1 < kRowsPerWave / G) {
+    if (it + 1 < RPW / G) {
       e0_n = __shfl(rp, lr + G);
       dg_n = __shfl(deg_l, lr + G);
       idx_n = -1;
@@ -494,16 +498,25 @@ int launch_spmm(const sagnn_spmm_plan* p, const float* X, int64_t ldx, int d, co
   const int64_t n_rows = p->info.n_rows;
   const int64_t n_chunks = p->info.n_chunks;
   const int64_t chunk_blocks = (n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
-  const int64_t rows_per_block = (int64_t)kWavesPerBlock * kRowsPerWave;
+  constexpr int G = kWave / LPR;
+  constexpr int RPW_SMALL = G > 4 ? G : 4;        // one row per lane group (at least 4 rows)
+  const bool small = n_rows < kSmallRows;
+  const int64_t rows_per_block = (int64_t)kWavesPerBlock * (small ? RPW_SMALL : kRowsPerWave);
   const int64_t row_blocks = (n_rows + rows_per_block - 1) / rows_per_block;
   const int64_t blocks = chunk_blocks + row_blocks;
   if (blocks > INT32_MAX) return sagnn::fail(SAGNN_ERR_ARG, "grid too large");
   if (blocks > 0) {
     sagnn::ProfileScope prof(sagnn::kProfSpmmRows, stream, p->info.nnz, n_rows);
-    hipLaunchKernelGGL(spmm_rows_kernel<LPR>, dim3((unsigned)blocks), dim3(kBlock), 0, stream,
-                       p->d_rowptr, p->d_colidx, X, ldx, d, n_rows, p->info.short_thresh,
-                       p->info.long_thresh, p->d_chunk_e0, p->d_chunk_e1, n_chunks,
-                       (int)chunk_blocks, partial, ep);
+    if (small)
+      hipLaunchKernelGGL((spmm_rows_kernel<LPR, RPW_SMALL>), dim3((unsigned)blocks), dim3(kBlock), 0, stream,
+                         p->d_rowptr, p->d_colidx, X, ldx, d, n_rows, p->info.short_thresh,
+                         p->info.long_thresh, p->d_chunk_e0, p->d_chunk_e1, n_chunks,
+                         (int)chunk_blocks, partial, ep);
+    else
+      hipLaunchKernelGGL((spmm_rows_kernel<LPR, kRowsPerWave>), dim3((unsigned)blocks), dim3(kBlock), 0, stream,
+                         p->d_rowptr, p->d_colidx, X, ldx, d, n_rows, p->info.short_thresh,
+                         p->info.long_thresh, p->d_chunk_e0, p->d_chunk_e1, n_chunks,
+                         (int)chunk_blocks, partial, ep);
     SAGNN_HIP_TRY(hipGetLastError());
   }
   const int64_t n_long = p->info.n_long_rows;
