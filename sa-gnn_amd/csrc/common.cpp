@@ -44,6 +44,11 @@ bool force_f32_mfma() {
   return v && strcmp(v, "f32") == 0;
 }
 
+bool force_bf16x3() {
+  const char* v = getenv("SAGNN_GEMM");
+  return v && strcmp(v, "bf16x3") == 0;
+}
+
 int ensure_dynamic_lds(const void* kernel, size_t bytes) {
   static std::mutex mu;
   static std::map<std::pair<int, const void*>, size_t> done;   // (device, kernel) -> limit set there

@@ -48,6 +48,11 @@ int lstm_fwd_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t,
                    const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h, float* gates_out,
                    float* c_out, const float* h_init, int64_t ld_hi, const float* c_init, float* c_final,
                    hipStream_t s);
+// lstm_f16.hip: the same LSTM on the f16 matrix cores, operands split in two round-to-nearest pieces (default engine)
+bool lstm_f16_supported(int d);
+int lstm_fwd_f16(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W, const float* b,
+                 float forget_bias, const float* drop, float* h, int64_t ld_h, float* gates_out, float* c_out,
+                 const float* h_init, int64_t ld_hi, const float* c_init, float* c_final, hipStream_t s);
 // attn_split.hip: layer norm + Q|K|V + attention + mean with the products on the bf16 matrix cores
 bool mhsa_split_supported(int d, int t, int heads);
 int ln_mhsa_mean_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
@@ -60,6 +65,7 @@ int lstm_fwd_split128(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int
                       float forget_bias, float* h, int64_t ld_h, float* gates_out, float* c_out, const float* h_init,
                       int64_t ld_hi, const float* c_init, float* c_final, hipStream_t s);
 bool force_f32_mfma();  // SAGNN_GEMM=f32 in the environment: the exact-fp32 MFMA kernels (A/B reference)
+bool force_bf16x3();    // SAGNN_GEMM=bf16x3: the six-product bf16 form where the default is the three-product f16 one
 bool mhsa_mfma_supported(int d, int t, int heads);
 int ln_mhsa_mean_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
                       const float* gamma, const float* beta, float eps, int apply_ln, const float* Wq,

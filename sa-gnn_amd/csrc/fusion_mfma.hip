@@ -966,7 +966,11 @@ int lstm_fwd_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, 
                   float* gates_out, float* c_out, const float* h_init, int64_t ld_hi, const float* c_init,
                   float* c_final, hipStream_t s) {
   const bool save = gates_out != nullptr;
-  if (lstm_split_supported(d) && !force_f32_mfma() && !(save && drop) && ld_h < (1 << 22) && (int64_t)t * d < (1 << 18))
+  const bool split_ok = !force_f32_mfma() && !(save && drop) && ld_h < (1 << 22) && (int64_t)t * d < (1 << 18);
+  if (lstm_f16_supported(d) && split_ok && !force_bf16x3())
+    return lstm_fwd_f16(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, h_init, ld_hi, c_init,
+                        c_final, s);
+  if (lstm_split_supported(d) && split_ok)
     return lstm_fwd_split(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, h_init, ld_hi,
                           c_init, c_final, s);
   // 32-row tiles are addressed with 32-bit byte offsets from a per-tile base

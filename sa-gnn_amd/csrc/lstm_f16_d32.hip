@@ -1,0 +1,9 @@
+// Split-f16 interval LSTM, d = 32, inference (with and without an output-dropout mask).
+#include "lstm_f16_kernel.h"
+
+namespace sagnn {
+int lstm_f16_d32(SAGNN_LSTM_F16_ARGS) {
+  if (drop) return launch_lstm_f16<32, false, true>(SAGNN_LSTM_F16_PASS);
+  return launch_lstm_f16<32, false, false>(SAGNN_LSTM_F16_PASS);
+}
+}  // namespace sagnn

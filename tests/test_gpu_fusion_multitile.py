@@ -129,22 +129,24 @@ def test_attn_bwd_front_many_tiles_per_block(dev, d, t, n):
 
 
 @pytest.mark.parametrize("d,t,n", [(64, 3, 20_011), (32, 16, 9_001), (128, 6, 10_007)])
-def test_split_bf16_engine_matches_f32_mfma_engine(dev, d, t, n, monkeypatch):
-    """The fusion GEMMs run on the bf16 matrix cores over EXACTLY split fp32 operands (x = x1 + x2 + x3, six piece
-    products). That is fp32 arithmetic, not a bf16 GEMM: against the round-1 engine (v_mfma_f32_32x32x2_f32, an fmaf
-    chain; SAGNN_GEMM=f32; at d = 128 the VALU LSTM + f32-MFMA dense products) the outputs differ by a few 1e-7 on h
-    and 1e-6 on the fused rows, and both are equally far from the float64 result."""
+def test_split_engines_match_f32_mfma_engine(dev, d, t, n, monkeypatch):
+    """The fusion GEMMs run on the 16-bit matrix cores over SPLIT fp32 operands: by default two round-to-nearest f16
+    pieces and three piece products (LSTM at d = 32 / 64), SAGNN_GEMM=bf16x3 three exact bf16 pieces and six products
+    (the attention products and the d = 128 LSTM use this form in both modes). Either is fp32-grade arithmetic, not a
+    half-precision GEMM: against the round-1 engine (v_mfma_f32_32x32x2_f32, an fmaf chain; SAGNN_GEMM=f32; at d = 128
+    the VALU LSTM + f32-MFMA dense products) the outputs differ by a few 1e-7 on h and 1e-6 on the fused rows, and all
+    are equally far from the float64 result."""
     from sa_gnn_amd import ops
     rng = np.random.default_rng(d + t)
     x = rng.standard_normal((n, t, d)).astype(np.float32)
     p, pd = _params(d, rng, dev)
     xd = torch.from_numpy(x).to(dev)
     outs = {}
-    for mode in ("split", "f32"):
-        if mode == "f32":
-            monkeypatch.setenv("SAGNN_GEMM", "f32")
-        else:
+    for mode in ("f16x2", "bf16x3", "f32"):
+        if mode == "f16x2":
             monkeypatch.delenv("SAGNN_GEMM", raising=False)
+        else:
+            monkeypatch.setenv("SAGNN_GEMM", mode)
         h = ops.lstm_fwd(xd, pd["lstm_W"], pd["lstm_b"], 1.0)
         f = ops.ln_mhsa_mean(h, pd["ln_gamma"], pd["ln_beta"], pd["Wq"], pd["bq"], pd["Wk"], pd["bk"], pd["Wv"], pd["bv"], 16)
         outs[mode] = (h.cpu().numpy().astype(np.float64), f.cpu().numpy().astype(np.float64))
@@ -153,8 +155,63 @@ def test_split_bf16_engine_matches_f32_mfma_engine(dev, d, t, n, monkeypatch):
     h64 = O.basic_lstm(x64, p64["lstm_W"], p64["lstm_b"], 1.0)
     f64 = O.mhsa(O.layer_norm_td(h64, p64["ln_gamma"], p64["ln_beta"]), p64["Wq"], p64["bq"], p64["Wk"], p64["bk"], p64["Wv"],
                  p64["bv"], 16).mean(axis=1)
-    assert np.abs(outs["split"][0] - outs["f32"][0]).max() <= 5e-6
-    assert np.abs(outs["split"][1] - outs["f32"][1]).max() <= 2e-5
-    e_split = max(np.abs(outs["split"][0] - h64).max(), np.abs(outs["split"][1] - f64).max())
     e_f32 = max(np.abs(outs["f32"][0] - h64).max(), np.abs(outs["f32"][1] - f64).max())
-    assert e_split <= 2e-5 and e_split <= 3 * e_f32 + 1e-6, (e_split, e_f32)
+    for mode in ("f16x2", "bf16x3"):
+        assert np.abs(outs[mode][0] - outs["f32"][0]).max() <= 5e-6, mode
+        assert np.abs(outs[mode][1] - outs["f32"][1]).max() <= 2e-5, mode
+        e_split = max(np.abs(outs[mode][0] - h64).max(), np.abs(outs[mode][1] - f64).max())
+        assert e_split <= 2e-5 and e_split <= 3 * e_f32 + 1e-6, (mode, e_split, e_f32)
+
+
+@pytest.mark.parametrize("d,t,n", [(64, 3, 1_000), (32, 4, 777), (64, 2, 40_003)])
+def test_lstm_inputs_beyond_the_f16_range(dev, d, t, n):
+    """The f16 pieces of the default LSTM engine hold |v| <= 65504. A workgroup that meets a larger x (here 1e6 and
+    3e38 in a few rows, next to ordinary and to tiny rows) re-evaluates its 96-row tile with fp32 fmaf chains
+    (lstm_f16_kernel.h): every row — the huge ones, their tile neighbours and the untouched tiles — must still match the
+    oracle, as TF's fp32 MatMul would."""
+    from sa_gnn_amd import ops
+    rng = np.random.default_rng(5 * d + t)
+    x = rng.standard_normal((n, t, d)).astype(np.float32)
+    x[5, 0, 3] = 1e6
+    x[5, t - 1, :] = -2e5
+    x[n // 2, 1, 7] = 3e38
+    x[n - 1, 0, :] *= 1e5
+    x[7] *= 1e-7                                   # denormal heads: the residual piece carries the value
+    x[200 % n, :, :] *= 1e-30
+    p, pd = _params(d, rng, dev)
+    got = ops.lstm_fwd(torch.from_numpy(x).to(dev), pd["lstm_W"], pd["lstm_b"], 1.0)
+    want = O.basic_lstm(x.astype(np.float64), p["lstm_W"].astype(np.float64), p["lstm_b"].astype(np.float64), 1.0)
+    assert np.isfinite(got.cpu().numpy()).all()
+    _check(got, want.astype(np.float32), "lstm_fwd beyond the f16 range")
+
+
+def test_lstm_training_forward_beyond_the_f16_range(dev):
+    """Same for the training forward (stores gate activations and cell states) and for a continued state."""
+    from sa_gnn_amd import ops
+    d, t, n = 64, 3, 500
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n, t, d)).astype(np.float32)
+    x[100, 1, 5] = 7e4
+    p, pd = _params(d, rng, dev)
+    xd = torch.from_numpy(x).to(dev)
+    lib = ops._lib.load()
+    h = torch.empty((n, t, d), device=dev)
+    gates = torch.empty((n, t, 4 * d), device=dev)
+    cell = torch.empty((n, t, d), device=dev)
+    ops.check(lib.sagnn_lstm_fwd_train_f32(xd.data_ptr(), xd.stride(0), xd.stride(1), n, t, d, pd["lstm_W"].data_ptr(),
+                                           pd["lstm_b"].data_ptr(), 1.0, None, h.data_ptr(), t * d, gates.data_ptr(),
+                                           cell.data_ptr(), ops._stream()))
+    # the stored activations (sigmoid(i), tanh(j), sigmoid(f + 1), sigmoid(o)) and cell states, float64, as O.basic_lstm steps
+    x64, W64, b64 = x.astype(np.float64), p["lstm_W"].astype(np.float64), p["lstm_b"].astype(np.float64)
+    hh, cc = np.zeros((n, d)), np.zeros((n, d))
+    want_g, want_c = np.zeros((n, t, 4 * d)), np.zeros((n, t, d))
+    sig = lambda z: 1.0 / (1.0 + np.exp(-z))
+    for ts in range(t):
+        gi, gj, gf, go = np.split(np.concatenate([x64[:, ts], hh], axis=1) @ W64 + b64, 4, axis=1)
+        act = [sig(gi), np.tanh(gj), sig(gf + 1.0), sig(go)]
+        cc = cc * act[2] + act[0] * act[1]
+        hh = np.tanh(cc) * act[3]
+        want_g[:, ts], want_c[:, ts] = np.concatenate(act, axis=1), cc
+    _check(h, O.basic_lstm(x64, W64, b64, 1.0).astype(np.float32), "h")
+    _check(gates, want_g.astype(np.float32), "gates")
+    _check(cell, want_c.astype(np.float32), "cell")

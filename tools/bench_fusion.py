@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Times the interval-fusion kernels alone (LSTM, LN + MHSA + mean) at the roofline configuration's
-row count, for both GEMM engines: the default (bf16 matrix cores on exactly split fp32 operands) and
-SAGNN_GEMM=f32 (v_mfma_f32_32x32x2_f32), and prints how far the two results are apart and how far
-each is from the numpy oracle on a row slice.  python tools/bench_fusion.py [--n 15000000] [--t 2] [--d 64]"""
+row count, for the three GEMM engines: the default (f16 matrix cores, operands split in two round-to-nearest
+pieces, three piece products), SAGNN_GEMM=bf16x3 (bf16 matrix cores, three exact pieces, six products) and
+SAGNN_GEMM=f32 (v_mfma_f32_32x32x2_f32), and prints how far the results are apart and how far each is from
+the numpy oracle on a row slice.  python tools/bench_fusion.py [--n 15000000] [--t 2] [--d 64]"""
 import argparse
 import os
 import sys
@@ -39,11 +40,11 @@ def main():
     want_f = O.mhsa(O.layer_norm_td(want_h, pn["ln_gamma"], pn["ln_beta"]), pn["Wq"], pn["bq"], pn["Wk"], pn["bk"], pn["Wv"],
                     pn["bv"], 16).mean(axis=1)
     res = {}
-    for mode in ("split", "f32"):
-        if mode == "f32":
-            os.environ["SAGNN_GEMM"] = "f32"
-        else:
+    for mode in ("f16x2", "bf16x3", "f32"):
+        if mode == "f16x2":
             os.environ.pop("SAGNN_GEMM", None)
+        else:
+            os.environ["SAGNN_GEMM"] = mode
 
         def timed(fn):
             fn()
@@ -66,7 +67,7 @@ def main():
         res[mode] = (hh, ff, h[:, -1, :].double().abs().mean().item(), fused[0].double().abs().mean().item())
         flop_lstm = n * (16 * d * d * t - 8 * d * d)
         flop_attn = n * t * 6 * d * d
-        print(f"[{mode:5s}] n={n} t={t} d={d}: LSTM {lstm_ms[0]:.3f} ms (min {lstm_ms[1]:.3f}) = {flop_lstm / lstm_ms[0] / 1e9:.1f} TFLOP/s fp32-equivalent; "
+        print(f"[{mode:6s}] n={n} t={t} d={d}: LSTM {lstm_ms[0]:.3f} ms (min {lstm_ms[1]:.3f}) = {flop_lstm / lstm_ms[0] / 1e9:.1f} TFLOP/s fp32-equivalent; "
               f"LN+MHSA {attn_ms[0]:.3f} ms (min {attn_ms[1]:.3f}) = {flop_attn / attn_ms[0] / 1e9:.1f} TFLOP/s; "
               f"vs oracle (first {S} rows): h max abs err {np.abs(hh - want_h).max():.3e}, fused {np.abs(ff - want_f).max():.3e}", flush=True)
         if a.train:
@@ -79,12 +80,13 @@ def main():
                                                        p["lstm_b"].data_ptr(), 1.0, None, h.data_ptr(), t * d, gates.data_ptr(),
                                                        cell.data_ptr(), ops._stream()))
             tr = timed(train_fwd)
-            print(f"[{mode:5s}] training forward (stores gates + cell): {tr[0]:.3f} ms", flush=True)
+            print(f"[{mode:6s}] training forward (stores gates + cell): {tr[0]:.3f} ms", flush=True)
             del gates, cell
-    dh = np.abs(res["split"][0] - res["f32"][0]).max()
-    df = np.abs(res["split"][1] - res["f32"][1]).max()
-    print(f"split vs f32 engines: h max abs diff {dh:.3e}, fused max abs diff {df:.3e}; "
-          f"abs-mean of last h {res['split'][2]:.9f} / {res['f32'][2]:.9f}, of fused {res['split'][3]:.9f} / {res['f32'][3]:.9f}")
+    for mode in ("f16x2", "bf16x3"):
+        dh = np.abs(res[mode][0] - res["f32"][0]).max()
+        df = np.abs(res[mode][1] - res["f32"][1]).max()
+        print(f"{mode} vs f32 engines: h max abs diff {dh:.3e}, fused max abs diff {df:.3e}; "
+              f"abs-mean of last h {res[mode][2]:.9f} / {res['f32'][2]:.9f}, of fused {res[mode][3]:.9f} / {res['f32'][3]:.9f}")
 
 
 if __name__ == "__main__":
