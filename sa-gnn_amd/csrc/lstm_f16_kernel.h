@@ -90,23 +90,23 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // The interleaved operation list of `step`: kGateOps gate-math operations of one batch tile followed by
-// kXOps operations that split one 16-row pass of the next step's x into its LDS images. Transcendentals
-// take two issue slots of four cycles, everything else one; operations are dealt to the MFMA slots by
-// cumulative cost.
+// 2 x kXOps operations that split two 16-row passes of the next step's x into their LDS images. The ORDER in
+// which they are issued and the MFMA gap each one goes to come from a list scheduler over their dependency
+// graph (tools/gen_lstm_schedule.py): at most one transcendental per gap, an even share of the issue cycles,
+// and nothing reads a result of its own gap.
 constexpr int kGateOps = 118, kXOps = 13;
-__host__ __device__ constexpr int op_cost(int k) {
-  return ((k >= 17 && k < 33) || (k >= 49 && k < 65) || (k >= 81 && k < 85) || (k >= 89 && k < 93)) ? 2 : 1;
+#include "lstm_f16_schedule.inc"
+template <int NM, bool XO>
+__host__ __device__ constexpr int sched_start(int i) {
+  if (NM == 48) return XO ? kStart48X[i] : kStart48[i];
+  if (NM == 24) return XO ? kStart24X[i] : kStart24[i];
+  return XO ? kStart12X[i] : kStart12[i];
 }
-__host__ __device__ constexpr int op_cum(int k) {
-  int c = 0;
-  for (int j = 0; j < k; ++j) c += op_cost(j);
-  return c;
-}
-__host__ __device__ constexpr int first_op_of_slot(int i, int nm, int nops) {
-  const int tot = op_cum(nops);
-  int k = 0;
-  while (k < nops && op_cum(k) * nm / tot < i) ++k;
-  return k;
+template <int NM, bool XO>
+__host__ __device__ constexpr int sched_op(int pos) {
+  if (NM == 48) return XO ? kOrder48X[pos] : kOrder48[pos];
+  if (NM == 24) return XO ? kOrder24X[pos] : kOrder24[pos];
+  return XO ? kOrder12X[pos] : kOrder12[pos];
 }
 
 __device__ __forceinline__ void lds_barrier() {
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
       const int hid = 16 * wave + 4 * q_;
 
       f32x4 ahi[4], alo[4];            // tile in flight
-      int xw0[2], xw1[2], xoff;        // pieces of the x pass being written
-      float xq[4];
+      int xw0[2][2], xw1[2][2], xoff[2];   // pieces of the two x passes being written
+      float xq[2][4];
       f32x4 ga[4], gl[4];              // pre-activations of the tile whose gate math is being interleaved
       f32x4 dv;                        // dropout scale of that tile
       float tt[4][4], pr[4], cn[4], u[4], hn[4], hv[4], r1[4];
@@ -369,33 +369,34 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
           // LAST kBT / 2 tiles' gate math (tile PB + 1 carries passes 2 (PB - (kBT - 1 - kBT / 2)) and + 1), thousands of
           // cycles after their loads were issued at the top of the step. At the last step xr is stale and the
           // target buffer is never read: harmless, and branch-free.
-          constexpr int XP = 2 * (PB - (kBT - 1 - kBT / 2)) + (K - kGateOps) / kXOps;     // pass 0 .. NFILL-1
+          constexpr int PS = (K - kGateOps) / kXOps;                            // which of the tile's two passes
+          constexpr int XP = 2 * (PB - (kBT - 1 - kBT / 2)) + PS;               // pass 0 .. NFILL-1
           constexpr int X = (K - kGateOps) % kXOps;
           const float xv[4] = {xr[XP].x, xr[XP].y, xr[XP].z, xr[XP].w};
           const int xrow = XP * RPP + fr_;
           if constexpr (X == 0) {
-            xw0[0] = head2(xv[0], xv[1]);
+            xw0[PS][0] = head2(xv[0], xv[1]);
           } else if constexpr (X == 1) {
-            xw0[1] = head2(xv[2], xv[3]);
+            xw0[PS][1] = head2(xv[2], xv[3]);
           } else if constexpr (X < 6) {
             constexpr int i = X - 2;
-            xq[i] = resid<(i & 1)>(xw0[i >> 1], xv[i]);
+            xq[PS][i] = resid<(i & 1)>(xw0[PS][i >> 1], xv[i]);
           } else if constexpr (X == 6) {
-            xw1[0] = tail_lo(xq[0], k4096);
+            xw1[PS][0] = tail_lo(xq[PS][0], k4096);
           } else if constexpr (X == 7) {
-            xw1[0] = tail_hi(xw1[0], xq[1], k4096);
+            xw1[PS][0] = tail_hi(xw1[PS][0], xq[PS][1], k4096);
           } else if constexpr (X == 8) {
-            xw1[1] = tail_lo(xq[2], k4096);
+            xw1[PS][1] = tail_lo(xq[PS][2], k4096);
           } else if constexpr (X == 9) {
-            xw1[1] = tail_hi(xw1[1], xq[3], k4096);
+            xw1[PS][1] = tail_hi(xw1[PS][1], xq[PS][3], k4096);
           } else if constexpr (X == 10) {
             xmax = max3abs(xmax, xv[0], xv[1]);
           } else if constexpr (X == 11) {
             xmax = max3abs(xmax, xv[2], xv[3]);
-            xoff = xrow * (D * 2) + (((fc4_ >> 3) ^ swz<D>(xrow)) << 4) + ((fc4_ >> 2) & 1) * 8;
+            xoff[PS] = xrow * (D * 2) + (((fc4_ >> 3) ^ swz<D>(xrow)) << 4) + ((fc4_ >> 2) & 1) * 8;
           } else {
-            *reinterpret_cast<i32x2*>(Xnxt + xoff) = i32x2{xw0[0], xw0[1]};
-            *reinterpret_cast<i32x2*>(Xnxt + PLANE + xoff) = i32x2{xw1[0], xw1[1]};
+            *reinterpret_cast<i32x2*>(Xnxt + xoff[PS]) = i32x2{xw0[PS][0], xw0[PS][1]};
+            *reinterpret_cast<i32x2*>(Xnxt + PLANE + xoff[PS]) = i32x2{xw1[PS][0], xw1[PS][1]};
           }
         }
       };
@@ -422,9 +423,11 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
                                                           __builtin_bit_cast(f16x8, bf[cur][0]), cin, 0, 0, 0);
         }
         if constexpr (BT > 0) {
-          constexpr int NOPS = kGateOps + (BT >= kBT - kBT / 2 ? 2 * kXOps : 0);
-          constexpr int lo = first_op_of_slot(I, NM, NOPS), hi = first_op_of_slot(I + 1, NM, NOPS);
-          static_for<lo, hi>([&](auto k_c) { gate_op(std::integral_constant<int, BT - 1>{}, k_c); });
+          constexpr bool XO = BT >= kBT - kBT / 2;     // this tile also carries two x passes
+          constexpr int lo = sched_start<NM, XO>(I), hi = sched_start<NM, XO>(I + 1);
+          static_for<lo, hi>([&](auto pos_c) {
+            gate_op(std::integral_constant<int, BT - 1>{}, std::integral_constant<int, sched_op<NM, XO>(decltype(pos_c)::value)>{});
+          });
         }
         __builtin_amdgcn_sched_barrier(0);
       };
@@ -436,7 +439,9 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
       read_b(0, 0, bf[0]);
       static_for<0, kBT>(tile_fn);
       // the last tile's gates: the only part of the step the MFMAs do not cover
-      static_for<0, kGateOps>([&](auto k_c) { gate_op(std::integral_constant<int, kBT - 1>{}, k_c); });
+      static_for<0, kGateOps>([&](auto pos_c) {
+        gate_op(std::integral_constant<int, kBT - 1>{}, std::integral_constant<int, kOrder48[decltype(pos_c)::value]>{});
+      });
     };
 
     for (int ts = 0; ts < t; ++ts) {

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--t", type=int, default=2)
     ap.add_argument("--d", type=int, default=64)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--engines", default="f16x2,bf16x3,f32", help="comma-separated subset of f16x2, bf16x3, f32")
     ap.add_argument("--train", action="store_true", help="also time the training forward (stores gates / cell)")
     a = ap.parse_args()
     from oracle import selfgnn_oracle as O
@@ -40,7 +41,8 @@ def main():
     want_f = O.mhsa(O.layer_norm_td(want_h, pn["ln_gamma"], pn["ln_beta"]), pn["Wq"], pn["bq"], pn["Wk"], pn["bk"], pn["Wv"],
                     pn["bv"], 16).mean(axis=1)
     res = {}
-    for mode in ("f16x2", "bf16x3", "f32"):
+    engines = a.engines.split(",")
+    for mode in engines:
         if mode == "f16x2":
             os.environ.pop("SAGNN_GEMM", None)
         else:
@@ -82,7 +84,7 @@ def main():
             tr = timed(train_fwd)
             print(f"[{mode:6s}] training forward (stores gates + cell): {tr[0]:.3f} ms", flush=True)
             del gates, cell
-    for mode in ("f16x2", "bf16x3"):
+    for mode in [m for m in engines if m != "f32" and "f32" in engines]:
         dh = np.abs(res[mode][0] - res["f32"][0]).max()
         df = np.abs(res[mode][1] - res["f32"][1]).max()
         print(f"{mode} vs f32 engines: h max abs diff {dh:.3e}, fused max abs diff {df:.3e}; "
