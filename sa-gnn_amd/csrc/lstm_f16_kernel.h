@@ -69,7 +69,9 @@ __device__ __forceinline__ int tail_hi(int s, float r, float k) {
   return s;
 }
 __device__ __forceinline__ float max3abs(float m, float a, float b) {
-  return __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));   // v_max3_f32 with |.| modifiers
+  float r;   // one instruction (fmaxf(fabsf(.)) costs a canonicalising v_max per operand); a NaN operand is ignored
+  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+  return r;
 }
 
 // 16-byte slot swizzle of the [row][D] 16-bit images (as in lstm_split_kernel.h)
