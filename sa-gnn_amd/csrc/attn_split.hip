@@ -1,29 +1,34 @@
 // layer_norm over (T, d) -> Q/K/V dense -> exp attention -> mean over queries, one pass over h
 // (reference model.py:152-155, Utils/attention.py:35-45, 55-78), with the three dense products on
-// the bf16 matrix cores over exactly split fp32 operands (see lstm_split.hip for the arithmetic:
-// x = x1 + x2 + x3 in bf16 pieces, six piece products, fp32 accumulation; not the reduced-precision
-// bf16 GEMM — the result is as close to the float64 product as an fp32 fmaf chain is).
+// the f16 matrix cores over split fp32 operands (f16_split.h: two round-to-nearest pieces per operand,
+// three piece products, fp32 accumulation; not a half-precision GEMM — the result is as close to the
+// float64 product as an fp32 fmaf chain is).
 //
 // A workgroup of NW = d/16 waves owns 64 GEMM rows = NB = 64/T nodes (row = nb*T + ts); it needs
-// ~76 KB of LDS and <= 256 registers, so TWO workgroups share a CU (two waves per SIMD): one's
+// ~68 KB of LDS and <= 256 registers, so TWO workgroups share a CU (two waves per SIMD): one's
 // attention phase (VALU + LDS latency) runs beside the other's products (matrix pipe).
 //   fill + layer norm: 16 threads per row (float4 each). Moments per row around the row's own mean
 //     (two passes in registers), combined over the T rows of a node with the exact pairwise
 //     formula (M2 = sum M2_r + d sum (mean_r - mean)^2): two workgroup barriers, no cancellation.
-//     The normalised rows go to LDS as three bf16 images [64][d] (B fragments).
+//     The normalised rows go to LDS as two f16 images [64][d] (B fragments).
 //   Q|K|V: transposed product (W^T y^T). Wave w owns output columns 16w..16w+15 of EACH of Q, K, V
 //     — with 16 heads these are whole heads — and keeps that slice of Wq/Wk/Wv in registers as A
-//     fragments. In the 16x16 C tile a lane holds 4 consecutive columns of one row: d_k = 4 -> the
+//     fragments; Wq and bq carry the score scale log2(e) / sqrt(d_k), so the scores leave as exp2 arguments.
+//     In the 16x16 C tile a lane holds 4 consecutive columns of one row: d_k = 4 -> the
 //     q, k and v vectors of ONE head; they go to a wave-private LDS table [4][64 rows][q|k|v].
 //   attention: LP lanes (1 for T <= 6, 2 for T = 8 / 12, 4 for T = 16) own one (node, head) pair and
-//     split its queries; the pair's T q/k/v vectors are T contiguous 48-byte records, keys are taken
-//     in chunks of <= 8 (plain sums of exp: chunking needs no rescaling), the partial results of the
-//     LP lanes meet through the table, and the d_k outputs leave as one vector store.
+//     split its queries; the pair's T q/k/v vectors are T contiguous 48-byte records. The mean over the
+//     queries is taken BEFORE the values are touched: out = sum_s w_s v_s with w_s = sum_t e_ts / (sum_s' e_ts' + 1e-8)
+//     / T — one multiply-add per (query, key) pair instead of d_k. Keys and values are taken in chunks of
+//     <= 8, the partial results of the LP lanes meet through the table, and the d_k outputs leave as one
+//     vector store.
+//   A y or W value beyond the f16 range (|v| > 65504: no sane layer norm produces one) makes the workgroup
+//     redo that tile's Q|K|V records with fp32 fmaf chains (slow_records).
 #include "common.h"
+#include "f16_split.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -32,20 +37,6 @@ constexpr int kRows = 64;
 constexpr int kBT = 4;
 constexpr int kRec = 48;   // bytes of one (row, 4-column group) record: q[4] | k[4] | v[4]
 
-struct Pieces {
-  float p1, p2, p3;
-};
-__device__ __forceinline__ Pieces split3(float x) {
-  Pieces s;
-  s.p1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u);
-  const float r = x - s.p1;
-  s.p2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r) & 0xFFFF0000u);
-  s.p3 = r - s.p2;
-  return s;
-}
-__device__ __forceinline__ int pack_hi(float lo, float hi) {
-  return (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
-}
 template <int D>
 __device__ __forceinline__ int swz(int row) {
   if (D == 128) return row & 15;      // 256-byte rows all start on bank 0
@@ -111,10 +102,11 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
   typedef typename HeadVec<DK>::type vec;
 
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  char* const Yp = lds;                                     // 3 images
-  char* const QKV = lds + 3 * PLANE;                        // NW tables
+  char* const Yp = lds;                                     // 2 images (heads, scaled residuals)
+  char* const QKV = lds + 2 * PLANE;                        // NW tables
   float2* const rstat = reinterpret_cast<float2*>(QKV + NW * QKVW);   // [64] (mean_r, M2_r)
   float2* const nstat = rstat + kRows;                      // [NB] (mean, rstd)
+  int* const flags = reinterpret_cast<int*>(nstat + NB);    // [0], [1]: |y| beyond the f16 range in the tile of that parity; [2]: in W
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, q = lane >> 4;
@@ -123,29 +115,42 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
   const int fr = tid / LPR, fc4 = (tid % LPR) * 4;
   char* const tab = QKV + wave * QKVW;
 
-  // ---- this wave's slices of Wq / Wk / Wv as A fragments: A[mm][k = 32 ks + 8 q + j] = W[k][16 wave + mm]
-  i32x4 wf[3][KS][3];
+  float k4096 = 4096.f;
+  asm volatile("" : "+v"(k4096));               // one register for the whole kernel, not a literal per use
+  if (tid < 3) flags[tid] = 0;
+  __syncthreads();
+  // exp(q.k / sqrt(d_k)) = exp2(q'.k) with q' = q log2(e) / sqrt(d_k): the factor rides in Wq and bq
+  const float qscale = 1.44269504088896340736f * (DK == 4 ? 0.5f : DK == 2 ? 0.70710678118654752440f : 0.35355339059327376220f);
+
+  // ---- this wave's slices of Wq / Wk / Wv as A fragments: A[mm][k = 32 ks + 8 q + j] = W[k][16 wave + mm],
+  // heads in wf[..][0], scaled residuals in wf[..][1]
+  i32x4 wf[3][KS][2];
   {
     const float* const Ws[3] = {Wq, Wk, Wv};
+    float wmax = 0.f;
 #pragma unroll
     for (int mat = 0; mat < 3; ++mat)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        Pieces pc[8];
+        float wv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pc[j] = split3(Ws[mat][(size_t)(32 * ks + 8 * q + j) * D + cbase + m]);
+        for (int j = 0; j < 8; ++j) {
+          wv[j] = Ws[mat][(size_t)(32 * ks + 8 * q + j) * D + cbase + m] * (mat == 0 ? qscale : 1.f);
+          wmax = __builtin_fmaxf(wmax, __builtin_fabsf(wv[j]));
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          wf[mat][ks][0][e] = pack_hi(pc[2 * e].p1, pc[2 * e + 1].p1);
-          wf[mat][ks][1][e] = pack_hi(pc[2 * e].p2, pc[2 * e + 1].p2);
-          wf[mat][ks][2][e] = pack_hi(pc[2 * e].p3, pc[2 * e + 1].p3);
+          const int hd = head2(wv[2 * e], wv[2 * e + 1]);
+          wf[mat][ks][0][e] = hd;
+          wf[mat][ks][1][e] = tail2(hd, wv[2 * e], wv[2 * e + 1], k4096);
         }
       }
+    if (wmax > kF16Max) flags[2] = 1;     // ordered before its first reader by the tile loop's barriers
   }
   f32x4 bias3[3];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    bias3[0][r] = bq[col0 + r];
+    bias3[0][r] = bq[col0 + r] * qscale;
     bias3[1][r] = bk[col0 + r];
     bias3[2][r] = bv[col0 + r];
   }
@@ -154,7 +159,6 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
     g4 = *reinterpret_cast<const float4*>(gamma + fc4);
     b4 = *reinterpret_cast<const float4*>(beta + fc4);
   }
-  const float scale = DK == 4 ? 0.5f : DK == 2 ? 0.70710678118654752440f : 0.35355339059327376220f;   // 1 / sqrt(d_k)
   const float inv_t = 1.f / (float)T;
 
   float4 xr[NFILL];
@@ -171,8 +175,10 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
   };
   fetch_tile(blockIdx.x);
 
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  int par = 0;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
     const int64_t node0 = tile * NB;
+    if (tid == 0) flags[par] = 0;   // two tiles (and their barriers) after its last reader
     int fr_ = fr, fc4_ = fc4, m_ = m, q_ = q;
     asm volatile("" : "+v"(fr_), "+v"(fc4_), "+v"(m_), "+v"(q_));
 
@@ -207,7 +213,8 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
       }
       lds_barrier();
     }
-    // ---- normalise, split into bf16 pieces, store the three images
+    // ---- normalise, split into f16 pieces, store the two images
+    float ymax = 0.f;
 #pragma unroll
     for (int p = 0; p < NFILL; ++p) {
       const int r = p * RPP + fr_;
@@ -220,48 +227,75 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
         y.z = xr[p].z * iz + (b4.z - st.x * iz);
         y.w = xr[p].w * iw + (b4.w - st.x * iw);
       }
-      const Pieces a = split3(y.x), b = split3(y.y), c = split3(y.z), d = split3(y.w);
+      ymax = max3abs(max3abs(ymax, y.x, y.y), y.z, y.w);
+      const int p0 = head2(y.x, y.y), p1 = head2(y.z, y.w);
       const int off = r * (D * 2) + (((fc4_ >> 3) ^ swz<D>(r)) << 4) + ((fc4_ >> 2) & 1) * 8;
-      *reinterpret_cast<i32x2*>(Yp + off) = i32x2{pack_hi(a.p1, b.p1), pack_hi(c.p1, d.p1)};
-      *reinterpret_cast<i32x2*>(Yp + PLANE + off) = i32x2{pack_hi(a.p2, b.p2), pack_hi(c.p2, d.p2)};
-      *reinterpret_cast<i32x2*>(Yp + 2 * PLANE + off) = i32x2{pack_hi(a.p3, b.p3), pack_hi(c.p3, d.p3)};
+      *reinterpret_cast<i32x2*>(Yp + off) = i32x2{p0, p1};
+      *reinterpret_cast<i32x2*>(Yp + PLANE + off) = i32x2{tail2(p0, y.x, y.y, k4096), tail2(p1, y.z, y.w, k4096)};
     }
     fetch_tile(tile + gridDim.x);   // next tile's rows, in flight under this tile's products and attention
     lds_barrier();
+    if (ymax > kF16Max) flags[par] = 1;   // after the barrier that follows tid 0's reset; read after the next one
 
     // ---- Q | K | V columns of this wave for every row of the tile -> the wave's table
 #pragma unroll
     for (int bt = 0; bt < kBT; ++bt) {
       const int row = bt * 16 + m_;
       const int sw = swz<D>(row);
-      f32x4 acc[3] = {bias3[0], bias3[1], bias3[2]};
+      f32x4 hi[3] = {bias3[0], bias3[1], bias3[2]};
+      f32x4 lo[3];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int off = row * (D * 2) + (((ks * 4 + q_) ^ sw) << 4);
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(Yp + off));
-        const bf16x8 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(Yp + PLANE + off));
-        const bf16x8 b3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(Yp + 2 * PLANE + off));
+        const f16x8 b1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(Yp + off));
+        const f16x8 b2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(Yp + PLANE + off));
 #pragma unroll
         for (int mat = 0; mat < 3; ++mat) {
-          const bf16x8 a1 = __builtin_bit_cast(bf16x8, wf[mat][ks][0]);
-          const bf16x8 a2 = __builtin_bit_cast(bf16x8, wf[mat][ks][1]);
-          const bf16x8 a3 = __builtin_bit_cast(bf16x8, wf[mat][ks][2]);
-          f32x4 v = acc[mat];
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, v, 0, 0, 0);
-          acc[mat] = v;
+          const f16x8 a1 = __builtin_bit_cast(f16x8, wf[mat][ks][0]);
+          const f16x8 a2 = __builtin_bit_cast(f16x8, wf[mat][ks][1]);
+          lo[mat] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : lo[mat], 0, 0, 0);
+          lo[mat] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, lo[mat], 0, 0, 0);
+          hi[mat] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, hi[mat], 0, 0, 0);
         }
       }
+      f32x4 acc[3];
+#pragma unroll
+      for (int mat = 0; mat < 3; ++mat)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mat][r] = fmaf(lo[mat][r], kLoInv, hi[mat][r]);
       char* rec = tab + q_ * GS + row * kRec + (row / T) * PN;
       *reinterpret_cast<f32x4*>(rec) = acc[0];
       *reinterpret_cast<f32x4*>(rec + 16) = acc[1];
       *reinterpret_cast<f32x4*>(rec + 32) = acc[2];
     }
     lds_barrier();   // table complete (wave-private), and every wave is done reading the y images
+    if (flags[par] | flags[2]) {
+      // ---- slow_records: a y or W value does not fit an f16 piece. The tile's Q|K|V records again as fp32 fmaf
+      // chains over y recomputed from x (the moments are still in LDS); thread per (row, matrix, column).
+      constexpr int NCOL = 16 * NW;
+      const float* const Ws[3] = {Wq, Wk, Wv};
+      const float* const bs[3] = {bq, bk, bv};
+      for (int idx = tid; idx < ROWS * 3 * NCOL; idx += NT) {
+        const int r = idx / (3 * NCOL), rem = idx - r * (3 * NCOL), mat = rem / NCOL, cl = rem - mat * NCOL;
+        const int nb = r / T, ts = r - nb * T;
+        if (node0 + nb >= n) continue;
+        const int col = 64 * (int)blockIdx.y + cl;
+        const float sc = mat == 0 ? qscale : 1.f;
+        const float2 st = apply_ln ? nstat[nb] : make_float2(0.f, 1.f);
+        const float* const xrow = x + (node0 + nb) * ld_n + (int64_t)ts * ld_t;
+        float acc = bs[mat][col] * sc;
+        for (int k = 0; k < D; ++k) {
+          float yv = xrow[k];
+          if (apply_ln) {
+            const float ik = st.y * gamma[k];
+            yv = yv * ik + (beta[k] - st.x * ik);
+          }
+          acc = fmaf(yv, Ws[mat][(size_t)k * D + col] * sc, acc);
+        }
+        *reinterpret_cast<float*>(QKV + (cl >> 4) * QKVW + ((cl >> 2) & 3) * GS + r * kRec + nb * PN + mat * 16 + (cl & 3) * 4) = acc;
+      }
+      __syncthreads();
+    }
 
     // ---- attention of each (node, head) pair of this wave's heads
     constexpr int PAIRS = NB * HPW;
@@ -274,22 +308,16 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
     for (int p = lane / LP; p < PAIRS; p += LSTEP) {
       const int hl = p % HPW, nb = p / HPW;
       char* base = tab + ((hl * DK) >> 2) * GS + nb * (T * kRec + PN) + ((hl * DK) & 3) * 4;   // DK = 8: groups 2 hl, 2 hl + 1
-      vec qv[TQ], ctx[TQ];
-      float rs[TQ];
+      vec qv[TQ];
+      float e[TQ][T], rs[TQ];
 #pragma unroll
-      for (int i = 0; i < TQ; ++i) {
-        qv[i] = HeadVec<DK>::load(base + (part * TQ + i) * kRec, GS) * scale;
-        ctx[i] = (vec)(0.f);
-        rs[i] = 0.f;
-      }
+      for (int i = 0; i < TQ; ++i) qv[i] = HeadVec<DK>::load(base + (part * TQ + i) * kRec, GS);
+      // e_ts = exp2(q'_t . k_s) for this lane's queries, all keys
 #pragma unroll
       for (int ch = 0; ch < T / KC; ++ch) {
-        vec k[KC], v[KC];
+        vec k[KC];
 #pragma unroll
-        for (int s = 0; s < KC; ++s) {
-          k[s] = HeadVec<DK>::load(base + (ch * KC + s) * kRec + 16, GS);
-          v[s] = HeadVec<DK>::load(base + (ch * KC + s) * kRec + 32, GS);
-        }
+        for (int s = 0; s < KC; ++s) k[s] = HeadVec<DK>::load(base + (ch * KC + s) * kRec + 16, GS);
 #pragma unroll
         for (int i = 0; i < TQ; ++i)
 #pragma unroll
@@ -297,14 +325,28 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
             float pd = qv[i][0] * k[s][0];
 #pragma unroll
             for (int c = 1; c < DK; ++c) pd = fmaf(qv[i][c], k[s][c], pd);
-            const float e = __expf(pd);
-            rs[i] += e;
-            ctx[i] += e * v[s];
+            const float ev = __builtin_amdgcn_exp2f(pd);
+            e[i][ch * KC + s] = ev;
+            rs[i] = (ch == 0 && s == 0) ? ev : rs[i] + ev;
           }
+      }
+      // the queries' mean taken on the weights: w_s = sum_t e_ts / (sum_s' e_ts' + 1e-8)
+      float w[T];
+#pragma unroll
+      for (int i = 0; i < TQ; ++i) {
+        const float inv = __builtin_amdgcn_rcpf(rs[i] + 1e-8f);
+#pragma unroll
+        for (int s = 0; s < T; ++s) w[s] = i == 0 ? e[0][s] * inv : fmaf(e[i][s], inv, w[s]);
       }
       vec o = (vec)(0.f);
 #pragma unroll
-      for (int i = 0; i < TQ; ++i) o += ctx[i] * __builtin_amdgcn_rcpf(rs[i] + 1e-8f);
+      for (int ch = 0; ch < T / KC; ++ch) {
+        vec v[KC];
+#pragma unroll
+        for (int s = 0; s < KC; ++s) v[s] = HeadVec<DK>::load(base + (ch * KC + s) * kRec + 32, GS);
+#pragma unroll
+        for (int s = 0; s < KC; ++s) o += w[ch * KC + s] * v[s];
+      }
       if (LP > 1) {
         // The LP partial sums meet through the wave's own table: lane `part` > 0 parks its o in the q slot
         // of the pair's record `part` (read into its owner's qv long ago: LDS operations of a wave
@@ -354,9 +396,9 @@ static int launch_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, c
   constexpr int NW = D >= 64 ? 4 : D / 16, NB = kRows / T;
   constexpr int LP = lanes_per_pair(T, D);
   constexpr int GS = kRows * kRec + NB * pad_node(T) + pad_group(T);
-  const size_t lds = (size_t)3 * kRows * D * 2 + (size_t)NW * 4 * GS + (size_t)(kRows + NB) * sizeof(float2);
+  const size_t lds = (size_t)2 * kRows * D * 2 + (size_t)NW * 4 * GS + (size_t)(kRows + NB) * sizeof(float2) + 16;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&ln_mhsa_split_kernel<D, T, LP>), lds)) return rc;
-  // d = 64 / 32: ~76 KB / ~38 KB of LDS and <= 256 registers -> two waves per SIMD; d = 128: ~98 KB, one workgroup
+  // d = 64 / 32: ~68 KB / ~34 KB of LDS and <= 256 registers -> two waves per SIMD; d = 128: ~82 KB, one workgroup
   // per CU for each of the two column halves
   const int per_cu = D == 128 ? 1 : D == 64 ? 2 : 4;
   constexpr int CB = D == 128 ? 2 : 1;

@@ -26,12 +26,10 @@
 
 #pragma once
 #include "common.h"
+#include "f16_split.h"
 
 namespace {
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -42,37 +40,6 @@ typedef int i32x2 __attribute__((ext_vector_type(2)));
 constexpr int kBT = SAGNN_LSTM_F16_BT;   // batch tiles of 16 rows per workgroup tile
 static_assert(kBT % 2 == 0 && kBT >= 4, "x passes ride two per tile on the last kBT / 2 tiles");
 constexpr int kRows = 16 * kBT;          // x and h both double-buffered in LDS: 8 images = 96 KB at d = 64, kBT = 6
-constexpr float kF16Max = 65504.f;
-constexpr float kLoInv = 1.f / 4096.f;
-
-// ---- the split, one instruction per function ----------------------------------------------------
-// heads of two floats (round to nearest), packed with the first in the low half
-__device__ __forceinline__ int head2(float a, float b) {
-  return __builtin_bit_cast(int, __builtin_convertvector((f32x2{a, b}), f16x2));   // v_cvt_pk_f16_f32
-}
-// a - (the low / high half of pk), exact
-template <int HI>
-__device__ __forceinline__ float resid(int pk, float a) {
-  float r;
-  if constexpr (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
-  else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
-  return r;
-}
-// rn16(r * k) into the low / high half of a pair
-__device__ __forceinline__ int tail_lo(float r, float k) {
-  int s;
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(s) : "v"(r), "v"(k));
-  return s;
-}
-__device__ __forceinline__ int tail_hi(int s, float r, float k) {
-  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(s) : "v"(r), "v"(k));
-  return s;
-}
-__device__ __forceinline__ float max3abs(float m, float a, float b) {
-  float r;   // one instruction (fmaxf(fabsf(.)) costs a canonicalising v_max per operand); a NaN operand is ignored
-  asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
-  return r;
-}
 
 // 16-byte slot swizzle of the [row][D] 16-bit images (as in lstm_split_kernel.h)
 template <int D>

@@ -130,9 +130,9 @@ def test_attn_bwd_front_many_tiles_per_block(dev, d, t, n):
 
 @pytest.mark.parametrize("d,t,n", [(64, 3, 20_011), (32, 16, 9_001), (128, 6, 10_007)])
 def test_split_engines_match_f32_mfma_engine(dev, d, t, n, monkeypatch):
-    """The fusion GEMMs run on the 16-bit matrix cores over SPLIT fp32 operands: by default two round-to-nearest f16
-    pieces and three piece products (LSTM at d = 32 / 64), SAGNN_GEMM=bf16x3 three exact bf16 pieces and six products
-    (the attention products and the d = 128 LSTM use this form in both modes). Either is fp32-grade arithmetic, not a
+    """The fusion GEMMs run on the 16-bit matrix cores over SPLIT fp32 operands: two round-to-nearest f16 pieces and
+    three piece products (the LSTM at d = 32 / 64 and the attention projections), or three exact bf16 pieces and six
+    products (the d = 128 LSTM; the d = 32 / 64 LSTM under SAGNN_GEMM=bf16x3). Either is fp32-grade arithmetic, not a
     half-precision GEMM: against the round-1 engine (v_mfma_f32_32x32x2_f32, an fmaf chain; SAGNN_GEMM=f32; at d = 128
     the VALU LSTM + f32-MFMA dense products) the outputs differ by a few 1e-7 on h and 1e-6 on the fused rows, and all
     are equally far from the float64 result."""
@@ -183,6 +183,29 @@ def test_lstm_inputs_beyond_the_f16_range(dev, d, t, n):
     want = O.basic_lstm(x.astype(np.float64), p["lstm_W"].astype(np.float64), p["lstm_b"].astype(np.float64), 1.0)
     assert np.isfinite(got.cpu().numpy()).all()
     _check(got, want.astype(np.float32), "lstm_fwd beyond the f16 range")
+
+
+@pytest.mark.parametrize("d,t,n", [(64, 16, 300), (32, 3, 1_000), (128, 6, 500), (64, 2, 20_001)])
+def test_attention_operands_beyond_the_f16_range(dev, d, t, n):
+    """The attention products run on f16 pieces as well. A layer-norm gain of 4e4 puts y beyond 65504 in most
+    tiles (every workgroup then rebuilds its Q|K|V records with fp32 fmaf chains); with the projections scaled down
+    by the same factor the scores stay ordinary, so the result is checked against the oracle at full accuracy."""
+    from sa_gnn_amd import ops
+    rng = np.random.default_rng(3 * d + t)
+    x = rng.standard_normal((n, t, d)).astype(np.float32)
+    x[n // 3] *= 30.0                                # a spiky node: its normalised rows reach |y| ~ 1e5
+    p = O.init_fusion_params(d, rng)
+    p["ln_gamma"] = (p["ln_gamma"] * 4e4).astype(np.float32)
+    for k in ("Wq", "Wk", "Wv"):
+        p[k] = (p[k] * 2.5e-5).astype(np.float32)
+    pd = {k: torch.from_numpy(v).to(dev) for k, v in p.items()}
+    got = ops.ln_mhsa_mean(torch.from_numpy(x).to(dev), pd["ln_gamma"], pd["ln_beta"], pd["Wq"], pd["bq"], pd["Wk"],
+                           pd["bk"], pd["Wv"], pd["bv"], 16)
+    p64 = {k: v.astype(np.float64) for k, v in p.items()}
+    y = O.layer_norm_td(x.astype(np.float64), p64["ln_gamma"], p64["ln_beta"])
+    assert np.abs(y).max() > 65504
+    want = O.mhsa(y, p64["Wq"], p64["bq"], p64["Wk"], p64["bk"], p64["Wv"], p64["bv"], 16).mean(axis=1)
+    _check(got, want.astype(np.float32), "ln_mhsa_mean beyond the f16 range")
 
 
 def test_lstm_training_forward_beyond_the_f16_range(dev):
