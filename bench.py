@@ -501,7 +501,9 @@ def main():
         idx = np.empty((ne, 2), dtype=np.int32)
         idx[:, 0] = np.repeat(np.arange(S, dtype=np.int32), np.diff(rp))
         idx[:, 1] = ci
-        src = emb[0][1].detach().cpu().numpy()
+        # the training stage moved the tables into its leaves (and Adam has stepped them: any values serve the check)
+        emb0 = (leaves["uEmbed"][0], leaves["iEmbed"][0]) if a.stages == "train" else emb[0]
+        src = emb0[1].detach().cpu().numpy()
         threads = tf1_path.max_threads()
         scratch = np.empty((max(ne, 1), d), dtype=np.float32)
         tf1_path.message_propagate(idx, src, S, 0.5, threads=threads, scratch=scratch)      # warm-up
@@ -511,7 +513,7 @@ def main():
             cpu_out = tf1_path.message_propagate(idx, src, S, 0.5, threads=threads, scratch=scratch)
             times.append(time.perf_counter() - tc)
         sub = ops.SpmmPlan(rp.copy(), ci.copy(), S, I, device=dev, validate=False)
-        gpu_out = ops.spmm(sub, emb[0][1].detach(), 0.5).cpu().numpy()
+        gpu_out = ops.spmm(sub, emb0[1].detach(), 0.5).cpu().numpy()
         err = float(np.abs(gpu_out - cpu_out).max())
         # the stronger single-thread CPU point of SURVEY §8d: scipy CSR @ dense, same rows
         A = sp.csr_matrix((np.ones(ne, np.float32), ci, rp), shape=(S, I))
