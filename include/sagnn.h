@@ -240,14 +240,12 @@ int sagnn_gnn_interval_bwd_f32(const sagnn_spmm_plan* plan_user, const sagnn_spm
  *
  * ARITHMETIC of the GEMM-shaped stages (the gate product [x_t | h] W and the three dense layers)
  *   for d in {32, 64, 128}, 16 heads: fp32 in, fp32 out, evaluated on the 16-bit matrix cores over
- *   SPLIT operands. d = 32 / 64 and the dense layers at every d: two round-to-nearest f16 pieces per
- *   value (v = v1 + v2'/4096, representation error <= 2^-23 |v|), three piece products, fp32
- *   accumulation; a value beyond the f16 range (|v| > 65504) is detected in the kernel and the tile that
- *   holds it is re-evaluated with fp32 fmaf chains, so every finite input gets an fp32-grade result.
- *   The d = 128 LSTM: three exactly cut bf16 pieces (masking, no rounding), the six largest piece
- *   products; dropped < 2^-20 |a b|. Either way the result is as close to the float64 product as an
- *   fp32 fmaf chain, not bit-identical to one. Environment (A/B only): SAGNN_GEMM=bf16x3 selects the
- *   bf16 form for the d = 32 / 64 LSTM, SAGNN_GEMM=f32 the v_mfma_f32_32x32x2_f32 kernels (an fmaf chain
+ *   SPLIT operands: two round-to-nearest f16 pieces per value (v = v1 + v2'/4096, representation error
+ *   <= 2^-23 |v|), three piece products, fp32 accumulation; a value beyond the f16 range (|v| > 65504)
+ *   is detected in the kernel and the tile that holds it is re-evaluated with fp32 fmaf chains, so every
+ *   finite input gets an fp32-grade result: as close to the float64 product as an fp32 fmaf chain, not
+ *   bit-identical to one. Environment (A/B only): SAGNN_GEMM=bf16x3 selects, for the d = 32 / 64 LSTM,
+ *   three exactly cut bf16 pieces and the six largest piece products (dropped < 2^-20 |a b|), SAGNN_GEMM=f32 the v_mfma_f32_32x32x2_f32 kernels (an fmaf chain
  *   bit for bit; d = 32 / 64), SAGNN_FUSION=valu the VALU formulations. Results are deterministic run to
  *   run in every mode.
  * -------------------------------------------------------------------------------- */

@@ -1,57 +1,45 @@
-// Interval LSTM at d = 128 (BASELINE config 3: MovieLens, --latdim 128) on the bf16 matrix cores with
-// exactly split fp32 operands — the arithmetic of lstm_split.hip (x = x1 + x2 + x3 in bf16 pieces, six
-// piece products, fp32 accumulation), a different decomposition:
+// Interval LSTM at d = 128 (BASELINE config 3: MovieLens, --latdim 128) on the f16 matrix cores with
+// split fp32 operands — the arithmetic of lstm_f16_kernel.h (f16_split.h: two round-to-nearest f16 pieces,
+// three piece products into two fp32 accumulators), a different decomposition:
 //
-// at d = 128 a wave's slice of W[256, 512] for 16 hidden units is 384 registers of A fragments, so the
-// register-resident-W, LDS-resident-h design of lstm_split.hip does not fit. Here ONE LAUNCH PER STEP
+// at d = 128 a wave's slice of W[256, 512] for 16 hidden units is 256 registers of A fragments, so the
+// register-resident-W, LDS-resident-h design of lstm_f16_kernel.h does not fit. Here ONE LAUNCH PER STEP
 // computes h_t, c_t from x_t, h_{t-1}, c_{t-1} (the recurrence travels through HBM: 1.5 KB per row and
 // step against 0.8 MFLOP), and the work is cut over (row tiles) x (4 hidden slices of 32 units):
 //   * a workgroup of 4 waves owns one hidden slice for its row tiles (persistent over them); wave w owns
 //     8 hidden units. Its two M tiles interleave the gates: C row 4q + r of tile A is gate (r & 1) of
 //     hidden unit 2q + (r >> 1) with gates (i, j), tile B the same with (f, o) — so a lane holds i, j, f, o
-//     of TWO hidden units of one row, and the wave's W slice is 2 tiles x 8 k-steps x 3 pieces = 192
-//     registers, resident for the whole launch;
-//   * x_t and h_{t-1} of a 64-row tile are split into pieces and shared through LDS as three bf16 images
+//     of TWO hidden units of one row, and the wave's W slice is 2 tiles x 8 k-steps x 2 pieces = 128
+//     registers, resident for the whole launch; two workgroups share a CU (64 KB of LDS each), so one's
+//     gate math runs beside the other's products;
+//   * x_t and h_{t-1} of a 64-row tile are split into pieces and shared through LDS as two f16 images
 //     [64][256] (16-byte slots XOR-swizzled with the row: 512-byte rows start on the same bank);
+//   * a tile that met a value beyond the f16 range (or W holding one) is evaluated again by the same lanes
+//     with fp32 fmaf chains (they still hold their c_{t-1}) and stored over the fast pass's results;
 //   * c_t is kept in the caller's h buffer one interval AHEAD (slot ts + 1 is free until step ts + 1
 //     writes h there; the same lane reads c and then writes h at those addresses), so the entry needs no
 //     workspace; with saved cell states (training) it is read from / written to them instead.
 // Output dropout is not offered here (the recurrent h would need a second copy): callers with a mask use
-// the VALU kernel. Reference: model.py:135-146, TF 1.14 BasicLSTMCell (see lstm_split.hip).
+// the VALU kernel. Reference: model.py:135-146, TF 1.14 BasicLSTMCell (see lstm_f16_kernel.h).
 #include "common.h"
+#include "f16_split.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int D = 128, NC = 4 * D, K2 = 2 * D;
 constexpr int kRows = 64, kBT = 4;
 constexpr int KS = K2 / 32;                  // 8 k-steps; the first 4 read x, the last 4 h
-constexpr int PLANE = kRows * K2 * 2;        // bytes of one bf16 image [64][256]
+constexpr int PLANE = kRows * K2 * 2;        // bytes of one f16 image [64][256]
 
-struct Pieces {
-  float p1, p2, p3;
-};
-__device__ __forceinline__ Pieces split3(float x) {
-  Pieces s;
-  s.p1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u);
-  const float r = x - s.p1;
-  s.p2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r) & 0xFFFF0000u);
-  s.p3 = r - s.p2;
-  return s;
-}
-__device__ __forceinline__ int pack_hi(float lo, float hi) {
-  return (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
-}
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // FIRST: zero state — h_{t-1} = 0 and c_{t-1} = 0 (h_prev / c_prev are not read, the h half is skipped).
 template <bool SAVE, bool FIRST>
-__global__ __launch_bounds__(256, 1) void lstm_step128_kernel(
+__global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
     const float* __restrict__ x_t, int64_t ld_x, const float* __restrict__ h_prev, int64_t ld_hp,
     const float* c_prev, int64_t ld_cp, const float* __restrict__ W, const float* __restrict__ bias,
     float forget_bias, float* h_out, int64_t ld_h, float* c_out, int64_t ld_c,
@@ -68,26 +56,36 @@ __global__ __launch_bounds__(256, 1) void lstm_step128_kernel(
 
   // ---- W slice as A fragments: A row mm = lane & 15 -> hidden hb + 2 (mm >> 2) + ((mm & 3) >> 1), gate 2 tile + (mm & 1);
   //      the gate's exp2 scale is folded in (lstm_split.hip)
-  i32x4 wf[2][KS][3];
+  int* const flags = reinterpret_cast<int*>(lds + 2 * PLANE);   // [0], [1]: value beyond the f16 range in the tile of that parity; [2]: in W
+  float k4096 = 4096.f;
+  asm volatile("" : "+v"(k4096));
+  if (tid < 3) flags[tid] = 0;
+  __syncthreads();
+  i32x4 wf[2][KS][2];
   {
     const int a_hid = hb + 2 * (m >> 2) + ((m & 3) >> 1);
+    float wmax = 0.f;
 #pragma unroll
     for (int tile = 0; tile < 2; ++tile) {
       const int gate = 2 * tile + (m & 1);
       const float sc = gate == 1 ? 2.f * kL2E : -kL2E;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        Pieces pc[8];
+        float wv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pc[j] = split3(W[(size_t)(32 * ks + 8 * q + j) * NC + gate * D + a_hid] * sc);
+        for (int j = 0; j < 8; ++j) {
+          wv[j] = W[(size_t)(32 * ks + 8 * q + j) * NC + gate * D + a_hid] * sc;
+          wmax = __builtin_fmaxf(wmax, __builtin_fabsf(wv[j]));
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          wf[tile][ks][0][e] = pack_hi(pc[2 * e].p1, pc[2 * e + 1].p1);
-          wf[tile][ks][1][e] = pack_hi(pc[2 * e].p2, pc[2 * e + 1].p2);
-          wf[tile][ks][2][e] = pack_hi(pc[2 * e].p3, pc[2 * e + 1].p3);
+          const int hd = head2(wv[2 * e], wv[2 * e + 1]);
+          wf[tile][ks][0][e] = hd;
+          wf[tile][ks][1][e] = tail2(hd, wv[2 * e], wv[2 * e + 1], k4096);
         }
       }
     }
+    if (wmax > kF16Max) flags[2] = 1;   // ordered before its first reader by the tile loop's barriers
   }
   f32x4 bc[2];   // k * (bias [+ forget bias]) per C row of the two tiles
 #pragma unroll
@@ -101,6 +99,7 @@ __global__ __launch_bounds__(256, 1) void lstm_step128_kernel(
 
   // fill mapping: 32 threads per row (float4 each), 8 rows per pass
   const int fr = tid >> 5, fc4 = (tid & 31) * 4;
+  float xmax = 0.f;   // largest |value| this thread moved into the images of the current tile
   auto fill_half = [&](const float* src, int64_t ld, int64_t row0, int rows_valid, int kbase) {
     float4 v[kRows / 8];
 #pragma unroll
@@ -112,52 +111,56 @@ __global__ __launch_bounds__(256, 1) void lstm_step128_kernel(
 #pragma unroll
     for (int p = 0; p < kRows / 8; ++p) {
       const int r = p * 8 + fr;
-      const Pieces a = split3(v[p].x), b = split3(v[p].y), c = split3(v[p].z), d = split3(v[p].w);
+      xmax = max3abs(max3abs(xmax, v[p].x, v[p].y), v[p].z, v[p].w);
+      const int p0 = head2(v[p].x, v[p].y), p1 = head2(v[p].z, v[p].w);
       const int col = kbase + fc4;
       const int off = r * (K2 * 2) + ((((col >> 3)) ^ (r & 31)) << 4) + ((col >> 2) & 1) * 8;
-      *reinterpret_cast<i32x2*>(lds + off) = i32x2{pack_hi(a.p1, b.p1), pack_hi(c.p1, d.p1)};
-      *reinterpret_cast<i32x2*>(lds + PLANE + off) = i32x2{pack_hi(a.p2, b.p2), pack_hi(c.p2, d.p2)};
-      *reinterpret_cast<i32x2*>(lds + 2 * PLANE + off) = i32x2{pack_hi(a.p3, b.p3), pack_hi(c.p3, d.p3)};
+      *reinterpret_cast<i32x2*>(lds + off) = i32x2{p0, p1};
+      *reinterpret_cast<i32x2*>(lds + PLANE + off) = i32x2{tail2(p0, v[p].x, v[p].y, k4096), tail2(p1, v[p].z, v[p].w, k4096)};
     }
   };
 
-  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  int par = 0;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, par ^= 1) {
     const int64_t row0 = tile * kRows;
     const int rows_valid = (int)(n - row0 < kRows ? n - row0 : kRows);
+    if (tid == 0) flags[par] = 0;   // two tiles (and their barriers) after its last reader
+    xmax = 0.f;
     fill_half(x_t, ld_x, row0, rows_valid, 0);
     if (!FIRST) fill_half(h_prev, ld_hp, row0, rows_valid, D);
     lds_barrier();
+    if (xmax > kF16Max) flags[par] = 1;   // after the barrier that follows the reset; read after the next one
 
     int m_ = m, q_ = q;
     asm volatile("" : "+v"(m_), "+v"(q_));
+    f32x2 cps[kBT];   // c_{t-1} of this lane's units: the slow pass needs it after h may have overwritten it
 #pragma unroll
     for (int bt = 0; bt < kBT; ++bt) {
       const int row = bt * 16 + m_;
       const bool live = row < rows_valid;
       f32x2 cp = {0.f, 0.f};
       if (!FIRST && live) cp = *reinterpret_cast<const f32x2*>(c_prev + (row0 + row) * ld_cp + hid);
-      f32x4 acc[2] = {bc[0], bc[1]};
+      cps[bt] = cp;
+      f32x4 hi[2] = {bc[0], bc[1]}, lo[2];
 #pragma unroll
       for (int ks = 0; ks < (FIRST ? KS / 2 : KS); ++ks) {
         const int off = row * (K2 * 2) + (((4 * ks + q_) ^ (row & 31)) << 4);
-        const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(lds + off));
-        const bf16x8 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(lds + PLANE + off));
-        const bf16x8 b3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(lds + 2 * PLANE + off));
+        const f16x8 b1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(lds + off));
+        const f16x8 b2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(lds + PLANE + off));
 #pragma unroll
         for (int tl = 0; tl < 2; ++tl) {
-          const bf16x8 a1 = __builtin_bit_cast(bf16x8, wf[tl][ks][0]);
-          const bf16x8 a2 = __builtin_bit_cast(bf16x8, wf[tl][ks][1]);
-          const bf16x8 a3 = __builtin_bit_cast(bf16x8, wf[tl][ks][2]);
-          f32x4 v = acc[tl];
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, v, 0, 0, 0);   // smallest terms first
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, v, 0, 0, 0);
-          v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, v, 0, 0, 0);
-          acc[tl] = v;
+          const f16x8 a1 = __builtin_bit_cast(f16x8, wf[tl][ks][0]);
+          const f16x8 a2 = __builtin_bit_cast(f16x8, wf[tl][ks][1]);
+          lo[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b1, ks == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : lo[tl], 0, 0, 0);
+          lo[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b2, lo[tl], 0, 0, 0);
+          hi[tl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, hi[tl], 0, 0, 0);
         }
       }
+      f32x4 acc[2];
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[tl][r] = fmaf(lo[tl][r], kLoInv, hi[tl][r]);
       // ---- gate math: acc[0] = (i, j) and acc[1] = (f, o) of hidden units hid, hid + 1; the MFMAs delivered k (pre + bias)
       f32x2 gi, gj, gf, go, cn, hn;
 #pragma unroll
@@ -183,6 +186,49 @@ __global__ __launch_bounds__(256, 1) void lstm_step128_kernel(
       }
     }
     lds_barrier();   // every wave has read the images before the next tile's fill
+    if (flags[par] | flags[2]) {
+      // ---- a value beyond the f16 range: this lane's rows and units again as fp32 fmaf chains, stored over the fast pass
+      __syncthreads();   // the fast pass's stores have left
+#pragma unroll 1
+      for (int bt = 0; bt < kBT; ++bt) {
+        const int row = bt * 16 + m_;
+        if (row >= rows_valid) continue;
+        const int64_t grow = row0 + row;
+        f32x2 act[4], cn, hn;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float a[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) a[g] = bias[g * D + hid + e] + (g == 2 ? forget_bias : 0.f);
+          for (int k = 0; k < D; ++k) {
+            const float xv = x_t[grow * ld_x + k];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a[g] = fmaf(xv, W[(size_t)k * NC + g * D + hid + e], a[g]);
+          }
+          if (!FIRST)
+            for (int k = 0; k < D; ++k) {
+              const float hv = h_prev[grow * ld_hp + k];
+#pragma unroll
+              for (int g = 0; g < 4; ++g) a[g] = fmaf(hv, W[(size_t)(D + k) * NC + g * D + hid + e], a[g]);
+            }
+          act[0][e] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * a[0]));
+          act[1][e] = fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.f * kL2E * a[1])), 1.f);
+          act[2][e] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * a[2]));
+          act[3][e] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * a[3]));
+          cn[e] = fmaf(cps[bt][e], act[2][e], act[0][e] * act[1][e]);
+          hn[e] = fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(cn[e] * (2.f * kL2E))), 1.f) * act[3][e];
+        }
+        *reinterpret_cast<f32x2*>(h_out + grow * ld_h + hid) = hn;
+        if (c_out) *reinterpret_cast<f32x2*>(c_out + grow * ld_c + hid) = cn;
+        if (SAVE) {
+          float* g = gates_out + grow * ld_g + hid;
+          *reinterpret_cast<f32x2*>(g) = act[0];
+          *reinterpret_cast<f32x2*>(g + D) = act[1];
+          *reinterpret_cast<f32x2*>(g + 2 * D) = act[2];
+          *reinterpret_cast<f32x2*>(g + 3 * D) = act[3];
+        }
+      }
+    }
   }
 }
 
@@ -196,10 +242,10 @@ template <bool SAVE, bool FIRST>
 static int launch_step(const float* x_t, int64_t ld_x, const float* h_prev, int64_t ld_hp, const float* c_prev,
                        int64_t ld_cp, const float* W, const float* b, float forget_bias, float* h_out, int64_t ld_h,
                        float* c_out, int64_t ld_c, float* gates_out, int64_t ld_g, int64_t n, hipStream_t s) {
-  const size_t lds = (size_t)3 * PLANE;   // 96 KB
+  const size_t lds = (size_t)2 * PLANE + 16;   // 64 KB + flags: two workgroups per CU
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_step128_kernel<SAVE, FIRST>), lds)) return rc;
   const int64_t n_tiles = (n + kRows - 1) / kRows;
-  const int64_t per_slice = cu_count_current() / 4 > 0 ? cu_count_current() / 4 : 1;   // 4 hidden slices share the CUs
+  const int64_t per_slice = cu_count_current() / 2 > 0 ? cu_count_current() / 2 : 1;   // 4 hidden slices share 2 workgroup slots per CU
   const int64_t bx = n_tiles < per_slice ? n_tiles : per_slice;
   hipLaunchKernelGGL((lstm_step128_kernel<SAVE, FIRST>), dim3((unsigned)bx, 4), dim3(256), lds, s, x_t, ld_x, h_prev,
                      ld_hp, c_prev, ld_cp, W, b, forget_bias, h_out, ld_h, c_out, ld_c, gates_out, ld_g, n, n_tiles);
