@@ -82,13 +82,16 @@ struct HeadVec<8> {
 
 // T: intervals (compile time). LP = lanes_per_pair(T, D). d = 128: a workgroup (4 waves) covers 64 of the 128
 // output columns of each of Q, K, V; blockIdx.y picks the half (the layer norm is evaluated by both).
-template <int D, int T, int LP>
+// BWD (front of the attention backward pass, LP = 1): `out` is the UPSTREAM gradient dL/d(mean context) [n, d] (read),
+// and the kernel writes dQ|dK|dV [n*t, 3D] (dqkv_out) and, when y_out is not NULL, the normalised rows y [n*t, D].
+template <int D, int T, int LP, bool BWD>
 __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void ln_mhsa_split_kernel(
     const float* __restrict__ x, int64_t ld_n, int64_t ld_t, int64_t n, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, int apply_ln, const float* __restrict__ Wq,
     const float* __restrict__ bq, const float* __restrict__ Wk, const float* __restrict__ bk,
-    const float* __restrict__ Wv, const float* __restrict__ bv, float* __restrict__ out, int64_t ld_out,
-    int64_t n_tiles) {
+    const float* __restrict__ Wv, const float* __restrict__ bv, float* out, int64_t ld_out,
+    int64_t n_tiles, float* __restrict__ dqkv_out, float* __restrict__ y_out) {
+  static_assert(!BWD || (LP == 1 && D <= 64), "the backward front keeps a pair in one lane");
   constexpr int NW = D >= 64 ? 4 : D / 16, NT = 64 * NW, KS = D / 32;
   constexpr int DK = D / 16;                    // 16 heads
   constexpr int HPW = 16 / DK;                  // heads per wave
@@ -228,6 +231,9 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
         y.w = xr[p].w * iw + (b4.w - st.x * iw);
       }
       ymax = max3abs(max3abs(ymax, y.x, y.y), y.z, y.w);
+      if constexpr (BWD) {
+        if (y_out && r < ROWS && node0 + r / T < n) *reinterpret_cast<float4*>(y_out + (node0 * T + r) * D + fc4_) = y;
+      }
       const int p0 = head2(y.x, y.y), p1 = head2(y.z, y.w);
       const int off = r * (D * 2) + (((fc4_ >> 3) ^ swz<D>(r)) << 4) + ((fc4_ >> 2) & 1) * 8;
       *reinterpret_cast<i32x2*>(Yp + off) = i32x2{p0, p1};
@@ -304,6 +310,74 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
     constexpr int KC = T <= 8 ? T : T / 2;           // keys per chunk
     static_assert(T % LP == 0 && T % KC == 0 && LP <= T, "query / key split");
     const int part = lane % LP;
+    if constexpr (BWD) {
+      // ---- backward of the attention of each pair, given g = dL/d(mean context) of its head (Utils/attention.py:55-78
+      // differentiated): a_s = g . v_s / T, p_ts = e_ts / (sum_s' e_ts' + 1e-8), dz_ts = p_ts (a_s - sum_s' p_ts' a_s'),
+      // dq_t = sum_s dz_ts k_s / sqrt(d_k), dk_s = sum_t dz_ts q_t / sqrt(d_k), dv_s = g / T sum_t p_ts. The table holds
+      // q' = q log2(e) / sqrt(d_k): dk_s = sum_t dz_ts q'_t / log2(e).
+      const float scale = qscale * 0.69314718055994530942f;
+#pragma unroll 1
+      for (int p = lane; p < PAIRS; p += 64) {
+        const int hl = p % HPW, nb = p / HPW;
+        const char* base = tab + ((hl * DK) >> 2) * GS + nb * (T * kRec + PN) + ((hl * DK) & 3) * 4;
+        const int64_t node = node0 + nb;
+        vec g = (vec)(0.f);
+        if (node < n) g = *reinterpret_cast<const vec*>(out + node * ld_out + cbase + hl * DK);
+        g *= inv_t;
+        vec qv[T], kv[T], vv[T], dk[T];
+        float ps[T], asum[T];
+#pragma unroll
+        for (int ts = 0; ts < T; ++ts) {
+          qv[ts] = HeadVec<DK>::load(base + ts * kRec, GS);
+          kv[ts] = HeadVec<DK>::load(base + ts * kRec + 16, GS);
+          vv[ts] = HeadVec<DK>::load(base + ts * kRec + 32, GS);
+          dk[ts] = (vec)(0.f);
+          asum[ts] = 0.f;
+          float pd = g[0] * vv[ts][0];
+#pragma unroll
+          for (int c = 1; c < DK; ++c) pd = fmaf(g[c], vv[ts][c], pd);
+          ps[ts] = pd;
+        }
+        float* const drow = dqkv_out + (node * T) * (3 * D) + cbase + hl * DK;
+#pragma unroll
+        for (int tq = 0; tq < T; ++tq) {
+          float a[T];
+          float rs = 0.f;
+#pragma unroll
+          for (int s_ = 0; s_ < T; ++s_) {
+            float z = qv[tq][0] * kv[s_][0];
+#pragma unroll
+            for (int c = 1; c < DK; ++c) z = fmaf(qv[tq][c], kv[s_][c], z);
+            a[s_] = __builtin_amdgcn_exp2f(z);
+            rs += a[s_];
+          }
+          const float inv = __builtin_amdgcn_rcpf(rs + 1e-8f);
+          float dot = 0.f;
+#pragma unroll
+          for (int s_ = 0; s_ < T; ++s_) {
+            a[s_] *= inv;
+            dot = fmaf(a[s_], ps[s_], dot);
+          }
+          vec dq = (vec)(0.f);
+#pragma unroll
+          for (int s_ = 0; s_ < T; ++s_) {
+            const float dz = a[s_] * (ps[s_] - dot);
+            dq += dz * kv[s_];
+            dk[s_] += dz * qv[tq];
+            asum[s_] += a[s_];
+          }
+          if (node < n) *reinterpret_cast<vec*>(drow + tq * (3 * D)) = dq * scale;
+        }
+        if (node < n) {
+#pragma unroll
+          for (int ts = 0; ts < T; ++ts) {
+            *reinterpret_cast<vec*>(drow + ts * (3 * D) + D) = dk[ts] * 0.69314718055994530942f;
+            *reinterpret_cast<vec*>(drow + ts * (3 * D) + 2 * D) = g * asum[ts];
+          }
+        }
+      }
+      continue;   // next tile
+    }
 #pragma unroll 1
     for (int p = lane / LP; p < PAIRS; p += LSTEP) {
       const int hl = p % HPW, nb = p / HPW;
@@ -389,15 +463,16 @@ bool mhsa_split_supported(int d, int t, int heads) {
   return (t >= 1 && t <= 6) || t == 8 || t == 12 || t == 16;
 }
 
-template <int D, int T>
+template <int D, int T, bool BWD = false>
 static int launch_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, const float* gamma, const float* beta,
                         float eps, int apply_ln, const float* Wq, const float* bq, const float* Wk, const float* bk,
-                        const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s) {
+                        const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s,
+                        float* dqkv = nullptr, float* y = nullptr) {
   constexpr int NW = D >= 64 ? 4 : D / 16, NB = kRows / T;
   constexpr int LP = lanes_per_pair(T, D);
   constexpr int GS = kRows * kRec + NB * pad_node(T) + pad_group(T);
   const size_t lds = (size_t)2 * kRows * D * 2 + (size_t)NW * 4 * GS + (size_t)(kRows + NB) * sizeof(float2) + 16;
-  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&ln_mhsa_split_kernel<D, T, LP>), lds)) return rc;
+  if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&ln_mhsa_split_kernel<D, T, LP, BWD>), lds)) return rc;
   // d = 64 / 32: ~68 KB / ~34 KB of LDS and <= 256 registers -> two waves per SIMD; d = 128: ~82 KB, one workgroup
   // per CU for each of the two column halves
   const int per_cu = D == 128 ? 1 : D == 64 ? 2 : 4;
@@ -406,8 +481,8 @@ static int launch_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, c
   const int64_t want = (int64_t)cu_count_current() * per_cu / CB;
   const int64_t blocks = n_tiles < want ? n_tiles : (want > 0 ? want : 1);
   ProfileScope prof(kProfMhsa, s, n, T);
-  hipLaunchKernelGGL((ln_mhsa_split_kernel<D, T, LP>), dim3((unsigned)blocks, CB), dim3(64 * NW), lds, s, x, ld_n, ld_t, n,
-                     gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, n_tiles);
+  hipLaunchKernelGGL((ln_mhsa_split_kernel<D, T, LP, BWD>), dim3((unsigned)blocks, CB), dim3(64 * NW), lds, s, x, ld_n, ld_t, n,
+                     gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, n_tiles, dqkv, y);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
@@ -434,6 +509,38 @@ int ln_mhsa_mean_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, in
   if (d == 128) return dispatch_t<128>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
   if (d == 64) return dispatch_t<64>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
   return dispatch_t<32>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
+}
+
+// Front of the attention backward pass on the same kernel (d in {32, 64}, 16 heads, t <= 6: one lane per pair):
+// y = LN(x) (or x), Q|K|V, attention backward -> dqkv [n*t, 3d] and, when y is not NULL, y [n*t, d].
+bool attn_bwd_front_split_supported(int d, int t, int heads) {
+  return heads == 16 && (d == 32 || d == 64) && t >= 1 && t <= 6;
+}
+
+template <int D>
+static int dispatch_bwd_t(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, const float* gamma, const float* beta,
+                          float eps, int apply_ln, const float* Wq, const float* bq, const float* Wk, const float* bk,
+                          const float* Wv, const float* bv, const float* g_out, int64_t ld_g, float* dqkv, float* y,
+                          hipStream_t s) {
+#define SAGNN_T_CASE(TT)                                                                                              \
+  case TT:                                                                                                            \
+    return launch_split<D, TT, true>(x, ld_n, ld_t, n, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv,            \
+                                     const_cast<float*>(g_out), ld_g, s, dqkv, y);
+  switch (t) {
+    SAGNN_T_CASE(1) SAGNN_T_CASE(2) SAGNN_T_CASE(3) SAGNN_T_CASE(4) SAGNN_T_CASE(5) SAGNN_T_CASE(6)
+    default: return fail(SAGNN_ERR_DIM, "split attention backward front: t = %d has no specialised kernel", t);
+  }
+#undef SAGNN_T_CASE
+}
+
+int attn_bwd_front_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads, const float* gamma,
+                         const float* beta, float eps, int apply_ln, const float* Wq, const float* bq, const float* Wk,
+                         const float* bk, const float* Wv, const float* bv, const float* g_out, int64_t ld_g, float* dqkv,
+                         float* y, hipStream_t s) {
+  if (!attn_bwd_front_split_supported(d, t, heads)) return fail(SAGNN_ERR_DIM, "split attention backward front: unsupported d/t/heads");
+  if (d == 64)
+    return dispatch_bwd_t<64>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, g_out, ld_g, dqkv, y, s);
+  return dispatch_bwd_t<32>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, g_out, ld_g, dqkv, y, s);
 }
 
 }  // namespace sagnn

@@ -1073,6 +1073,9 @@ int attn_bwd_front_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, i
                         const float* gamma, const float* beta, float eps, int apply_ln, const float* Wq,
                         const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
                         const float* g_out, int64_t ld_g, float* dqkv, float* y, hipStream_t s) {
+  if (attn_bwd_front_split_supported(d, t, heads) && !force_f32_mfma())
+    return attn_bwd_front_split(x, ld_n, ld_t, n, t, d, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, g_out, ld_g,
+                                dqkv, y, s);
   if (d == 64)
     return launch_attn_bwd_front<64>(x, ld_n, ld_t, n, t, heads, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, g_out, ld_g, dqkv, y, s);
   if (d == 32)
