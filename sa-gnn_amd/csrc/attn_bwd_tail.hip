@@ -271,6 +271,7 @@ extern "C" int sagnn_attn_bwd_tail_f32(float* y, const float* dqkv, int64_t rows
     return sagnn::fail(SAGNN_ERR_ALIGN, "attn_bwd_tail: need 16-byte aligned buffers");
   if (rows == 0) return SAGNN_OK;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (!sagnn::force_f32_mfma()) return sagnn::attn_bwd_tail_f16(y, dqkv, rows, d, Wqkv, dWqkv, dbqkv, s);
   if (d == 64) return launch<64>(y, dqkv, rows, Wqkv, dWqkv, dbqkv, s);
   return launch<32>(y, dqkv, rows, Wqkv, dWqkv, dbqkv, s);
 }

@@ -1,0 +1,303 @@
+// Tail of the attention backward pass on the f16 matrix cores (gradient of reference Utils/attention.py:31-45's
+// three dense layers), one pass over dQ|dK|dV:
+//
+//   dy [R, D]    = dQKV [R, 3D] @ Wqkv^T [3D, D]      (written over y: y is dead after this kernel)
+//   dWqkv [D,3D] += y^T [D, R] @ dQKV [R, 3D]
+//   dbqkv [3D]   += column sums of dQKV
+//
+// attn_bwd_tail.hip runs the two products on v_mfma_f32_32x32x2_f32 and is bound by it (15 ms per step of the
+// roofline workload). Here the operands are split as in f16_split.h (two round-to-nearest f16 pieces, three piece
+// products, fp32 accumulation) and the kernel is bound by its 1.3 KB of HBM traffic per row instead.
+//
+// A block (8 waves at D = 64: two per SIMD; 4 waves and two blocks per CU at D = 32) walks 32-row chunks. A chunk's y | dQ | dK | dV rows are split once and
+// kept as four [32][D] f16 sub-images (x 2 pieces, x 2 buffers = 64 KB at D = 64), 16-byte chunks XOR-swizzled
+// with the row. dy reads dQKV ROW-wise (ds_read_b128: 8 consecutive k of a row) against W^T fragments resident in
+// registers; dW sums over the chunk's ROWS, so both of its operands are read TRANSPOSED from the same images
+// (ds_read_b64_tr_b16: a 16-lane group fetches a 4-row x 16-column block and each lane receives one column —
+// no second copy, no cross-lane traffic). dW's 6 (3 at D = 32) head and residual accumulator tiles per wave live
+// across all chunks of the block and are flushed once with float atomics; db rides on the same product as a tile row of
+// ones. A chunk holding a value beyond the f16 range (|v| > 65504) takes no part in the MFMAs: the block evaluates
+// it with fp32 fmaf chains instead (a W holding one: every chunk).
+#include "common.h"
+#include "f16_split.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+constexpr int kRows = 32;
+
+// byte offset of 16-byte chunk `chunk` (8 columns) of row `row` in a [32][D] f16 sub-image
+template <int D>
+__device__ __forceinline__ int img_off(int row, int chunk) {
+  const int sw = D == 64 ? (row & 7) : ((row >> 1) & 3);
+  return row * (D * 2) + ((chunk ^ sw) << 4);
+}
+
+// Transposed operand: rows 8 kq .. 8 kq + 7 of column 16 ct + (lane & 15) of a sub-image, as 8 consecutive k of an
+// MFMA A / B operand. Lane 4 qq + pp of a 16-lane group supplies the address of row qq, columns 4 pp .. 4 pp + 3 of
+// each 4-row block and receives column (lane & 15) of its four rows.
+template <int D>
+__device__ __forceinline__ i32x4 read_tr(const char* sub, int ct, int lane) {
+  const int kq = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+  const char* p0 = sub + img_off<D>(8 * kq + qq, 2 * ct + (pp >> 1)) + 8 * (pp & 1);
+  const char* p1 = sub + img_off<D>(8 * kq + 4 + qq, 2 * ct + (pp >> 1)) + 8 * (pp & 1);
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
+  const i32x2 lo = __builtin_bit_cast(i32x2, a), hi = __builtin_bit_cast(i32x2, b);
+  return i32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+// db rides on the dW product as a tile row of ones (db[o] = sum_r 1 * dQKV[r][o]: the 32 rows of a chunk are summed inside the
+// MFMA, so a node's rows, whose dK sum to ~0, cancel before they meet the running total). Tile column b of a wave's NBW belongs
+// to the wave with wm = bias_owner(b); bias_slot(b) numbers an owner's columns.
+__host__ __device__ constexpr int bias_owner(int b, int nmt, int nbw) { return b * nmt / nbw; }
+__host__ __device__ constexpr int bias_slot(int b, int nmt, int nbw) {
+  int first = b;
+  while (first > 0 && bias_owner(first - 1, nmt, nbw) == bias_owner(b, nmt, nbw)) --first;
+  return b - first;
+}
+
+template <int D>
+__global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd_tail_f16_kernel(float* __restrict__ y, const float* __restrict__ dqkv,
+                                                                      int64_t rows, const float* __restrict__ W,
+                                                                      float* __restrict__ dW, float* __restrict__ db,
+                                                                      int64_t n_chunks) {
+  constexpr int Q3 = 3 * D;              // dQKV columns
+  constexpr int S4 = D;                  // float4 slots per staged row: y | dQKV = 4 D floats
+  constexpr int SUB = kRows * D * 2;     // bytes of one [32][D] f16 sub-image
+  constexpr int PIECE = 4 * SUB;         // y | dQ | dK | dV
+  constexpr int BUF = 2 * PIECE;         // heads, scaled residuals
+  constexpr int NWV = D / 8;             // waves per block: 8 at D = 64 (two per SIMD), 4 at D = 32 (two blocks per CU)
+  constexpr int kBlock = 64 * NWV;
+  constexpr int NV = kRows * S4 / kBlock;   // float4 per thread and chunk (4)
+  constexpr int NMT = D / 16, NNT = Q3 / 16;   // dW: NMT x NNT tiles of 16 x 16
+  constexpr int MB = 1;                  // dW tile rows per wave ...
+  constexpr int NBW = NMT * NNT / NWV;   // ... and tile columns per wave (6 / 3)
+  constexpr int KS1 = Q3 / 32;           // k-steps of dy (6 / 3)
+  constexpr int NT1 = D / 16;            // column tiles of dy (4 / 2)
+  constexpr int M1 = 1;                  // dy tiles per wave: (row tile wave / NT1, column tile wave % NT1)
+  static_assert(NV * kBlock == kRows * S4 && 2 * NT1 == NWV && NNT % (NWV / NMT) == 0, "unsupported D");
+
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int* const flags = reinterpret_cast<int*>(lds + 2 * BUF);   // [0], [1]: chunk number (+1) in that buffer if it is out of range; [2]: W is
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kq = lane >> 4;
+  float k4096 = 4096.f;
+  asm volatile("" : "+v"(k4096));
+  if (tid < 3) flags[tid] = 0;
+  __syncthreads();
+
+  // ---- dy: this wave's column tile of W^T as B fragments, resident: B[k = o][j] = Wqkv[16 nt1 + j][o]
+  const int nt1 = wave % NT1;
+  const int mt1_0 = wave / NT1;
+  i32x4 wf[KS1][2];
+  {
+    float wmax = 0.f;
+    const float* wrow = W + (size_t)(16 * nt1 + m) * Q3 + 8 * kq;
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+      const float4 a = *reinterpret_cast<const float4*>(wrow + 32 * ks), b = *reinterpret_cast<const float4*>(wrow + 32 * ks + 4);
+      const float wv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int hd = head2(wv[2 * e], wv[2 * e + 1]);
+        wf[ks][0][e] = hd;
+        wf[ks][1][e] = tail2(hd, wv[2 * e], wv[2 * e + 1], k4096);
+        wmax = max3abs(wmax, wv[2 * e], wv[2 * e + 1]);
+      }
+    }
+    if (wmax > kF16Max) flags[2] = 1;   // read after the barriers below
+  }
+  // ---- dW: my tiles (wm * MB + a, wn * NBW + b), head and residual accumulators
+  const int wm = wave % NMT, wn = wave / NMT;
+  f32x4 hiw[MB][NBW], low[MB][NBW];
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) hiw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}, low[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 hib[2], lob[2];                                  // db tiles of the columns I own (at most two)
+  hib[0] = hib[1] = lob[0] = lob[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const i32x4 ones = {0x3C003C00, 0x3C003C00, 0x3C003C00, 0x3C003C00};   // f16 1.0 in every A element: head 1, residual 0
+
+  float4 stage[NV];
+  auto fetch = [&](int64_t ch) {
+    const int64_t row0 = ch * kRows;
+    const int last = (int)(rows - 1 - row0 < kRows - 1 ? rows - 1 - row0 : kRows - 1);  // uniform
+    const float* ybase = y + row0 * D;
+    const float* gbase = dqkv + row0 * Q3;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int i = tid + v * kBlock;
+      const int r = i / S4, s = i - r * S4;
+      const uint32_t rc = r < last ? r : last;          // rows past the end read the last row, zeroed below
+      const float4 val = s < D / 4 ? *reinterpret_cast<const float4*>(ybase + (rc * D + 4 * s))
+                                   : *reinterpret_cast<const float4*>(gbase + (rc * Q3 + 4 * (s - D / 4)));
+      const bool ok = r <= last;
+      stage[v] = make_float4(ok ? val.x : 0.f, ok ? val.y : 0.f, ok ? val.z : 0.f, ok ? val.w : 0.f);
+    }
+  };
+  // split the staged rows into buffer `b`; `id` = chunk number + 1 marks the buffer if a value does not fit
+  auto commit = [&](int b, int id) {
+    char* const buf = lds + b * BUF;
+    float vmax = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int i = tid + v * kBlock;
+      const int r = i / S4, s = i - r * S4;
+      const int sub = s / (D / 4), c4 = s - sub * (D / 4);
+      const float4 x = stage[v];
+      const int p0 = head2(x.x, x.y), p1 = head2(x.z, x.w);
+      char* const dst = buf + sub * SUB + img_off<D>(r, c4 >> 1) + (c4 & 1) * 8;
+      *reinterpret_cast<i32x2*>(dst) = i32x2{p0, p1};
+      *reinterpret_cast<i32x2*>(dst + PIECE) = i32x2{tail2(p0, x.x, x.y, k4096), tail2(p1, x.z, x.w, k4096)};
+      vmax = max3abs(max3abs(vmax, x.x, x.y), x.z, x.w);
+    }
+    if (vmax > kF16Max) flags[b] = id;
+  };
+
+  int64_t ch = blockIdx.x;
+  int cur = 0;
+  if (ch < n_chunks) {
+    fetch(ch);
+    commit(0, (int)(ch + 1));
+  }
+  __syncthreads();
+  for (; ch < n_chunks; ch += gridDim.x) {
+    const int64_t nxt = ch + gridDim.x;
+    const bool slow = flags[cur] == (int)(ch + 1) || flags[2] != 0;   // block-uniform
+    if (nxt < n_chunks) fetch(nxt);  // lands under the MFMAs below
+    const char* const buf = lds + cur * BUF;
+    const int64_t row0 = ch * kRows;
+    const int rows_valid = (int)(rows - row0 < kRows ? rows - row0 : kRows);
+    int lane_ = lane, m_ = m, kq_ = kq;
+    asm volatile("" : "+v"(lane_), "+v"(m_), "+v"(kq_));
+
+    if (!slow) {
+      // ---- dW tiles += y^T dQKV (K = the chunk's 32 rows): both operands read transposed
+      {
+        i32x4 a1[MB], a2[MB];
+#pragma unroll
+        for (int a = 0; a < MB; ++a) {
+          a1[a] = read_tr<D>(buf, wm * MB + a, lane_);
+          a2[a] = read_tr<D>(buf + PIECE, wm * MB + a, lane_);
+        }
+#pragma unroll
+        for (int b = 0; b < NBW; ++b) {
+          const int col = 16 * (wn * NBW + b);              // dQKV column of the tile
+          const char* const sub = buf + (1 + col / D) * SUB;
+          const i32x4 b1 = read_tr<D>(sub, (col % D) / 16, lane_);
+          const i32x4 b2 = read_tr<D>(sub + PIECE, (col % D) / 16, lane_);
+#pragma unroll
+          for (int a = 0; a < MB; ++a) {
+            low[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a2[a]), __builtin_bit_cast(f16x8, b1), low[a][b], 0, 0, 0);
+            low[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a1[a]), __builtin_bit_cast(f16x8, b2), low[a][b], 0, 0, 0);
+            hiw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a1[a]), __builtin_bit_cast(f16x8, b1), hiw[a][b], 0, 0, 0);
+          }
+          if (bias_owner(b, NMT, NBW) == wm) {   // wave-uniform
+            const int sl = bias_slot(b, NMT, NBW);   // a constant once the loop is unrolled
+            lob[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ones), __builtin_bit_cast(f16x8, b2), lob[sl], 0, 0, 0);
+            hib[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ones), __builtin_bit_cast(f16x8, b1), hib[sl], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);   // one tile column's operands in flight at a time
+        }
+      }
+      // ---- dy[:, 16 nt1 .. + 15] = dQKV @ W^T for my row tiles: dQKV read row-wise
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(y + row0 * D, 0, rows_valid * D * 4, 0x00020000);
+#pragma unroll
+      for (int t1 = 0; t1 < M1; ++t1) {
+        const int mt = mt1_0 + t1;
+        const int row = 16 * mt + m_;
+        f32x4 hi = {0.f, 0.f, 0.f, 0.f}, lo = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+          const int col = 32 * ks;                          // + 8 kq: never crosses a sub-image (D % 32 == 0)
+          const char* const src = buf + (1 + col / D) * SUB + img_off<D>(row, (col % D) / 8 + kq_);
+          const f16x8 g1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(src));
+          const f16x8 g2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const i32x4*>(src + PIECE));
+          lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(g2, __builtin_bit_cast(f16x8, wf[ks][0]), lo, 0, 0, 0);
+          lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(g1, __builtin_bit_cast(f16x8, wf[ks][1]), lo, 0, 0, 0);
+          hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(g1, __builtin_bit_cast(f16x8, wf[ks][0]), hi, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // C layout: lane (n = lane & 15, mq = lane >> 4) holds rows 16 mt + 4 mq + r of column 16 nt1 + n
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, fmaf(lo[r], kLoInv, hi[r])), rs,
+                                                ((16 * mt + 4 * kq_ + r) * D + 16 * nt1 + m_) * 4, 0, 0);
+      }
+    } else {
+      // ---- a value beyond the f16 range in this chunk (or in W): fp32 fmaf chains. dW first (it reads y), then dy.
+      for (int idx = tid; idx < D * Q3; idx += kBlock) {
+        const int i = idx / Q3, o = idx - i * Q3;
+        float acc = 0.f;
+        for (int r = 0; r < rows_valid; ++r) acc = fmaf(y[(row0 + r) * D + i], dqkv[(row0 + r) * Q3 + o], acc);
+        atomicAdd(dW + idx, acc);
+      }
+      for (int o = tid; o < Q3; o += kBlock) {
+        float acc = 0.f;
+        for (int r = 0; r < rows_valid; ++r) acc += dqkv[(row0 + r) * Q3 + o];
+        atomicAdd(db + o, acc);
+      }
+      __syncthreads();
+      for (int idx = tid; idx < rows_valid * D; idx += kBlock) {
+        const int r = idx / D, i = idx - r * D;
+        float acc = 0.f;
+        for (int o = 0; o < Q3; ++o) acc = fmaf(dqkv[(row0 + r) * Q3 + o], W[(size_t)i * Q3 + o], acc);
+        y[(row0 + r) * D + i] = acc;
+      }
+    }
+    if (nxt < n_chunks) commit(cur ^ 1, (int)(nxt + 1));
+    __syncthreads();  // next buffer complete and marked; this one free next time round
+    cur ^= 1;
+  }
+
+  // ---- flush ------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int a = 0; a < MB; ++a)
+#pragma unroll
+    for (int b = 0; b < NBW; ++b) {
+      const int mt = wm * MB + a, nt = wn * NBW + b;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        atomicAdd(dW + (size_t)(16 * mt + 4 * kq + r) * Q3 + 16 * nt + m, fmaf(low[a][b][r], kLoInv, hiw[a][b][r]));
+    }
+#pragma unroll
+  for (int b = 0; b < NBW; ++b)
+    if (bias_owner(b, NMT, NBW) == wm && kq == 0) {   // every C row of a ones tile holds the column sums: row 0 speaks
+      const int sl = bias_slot(b, NMT, NBW);
+      const float v0 = fmaf(sl == 0 ? lob[0][0] : lob[1][0], kLoInv, sl == 0 ? hib[0][0] : hib[1][0]);
+      atomicAdd(db + 16 * (wn * NBW + b) + m, v0);
+    }
+}
+
+template <int D>
+int launch(float* y, const float* dqkv, int64_t rows, const float* W, float* dW, float* db, hipStream_t s) {
+  const size_t lds = (size_t)2 * 2 * 4 * kRows * D * 2 + 16;   // 64 KB at D = 64: two blocks per CU
+  if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_tail_f16_kernel<D>), lds)) return rc;
+  const int64_t n_chunks = (rows + kRows - 1) / kRows;
+  const int64_t want = (D == 64 ? 1 : 2) * (int64_t)sagnn::cu_count_current();
+  const int64_t blocks = n_chunks < want ? n_chunks : want;
+  hipLaunchKernelGGL(attn_bwd_tail_f16_kernel<D>, dim3((unsigned)blocks), dim3(D == 64 ? 512 : 256), lds, s, y, dqkv, rows, W, dW,
+                     db, n_chunks);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
+}  // namespace
+
+namespace sagnn {
+
+int attn_bwd_tail_f16(float* y, const float* dqkv, int64_t rows, int d, const float* Wqkv, float* dWqkv, float* dbqkv,
+                      hipStream_t s) {
+  if (d == 64) return launch<64>(y, dqkv, rows, Wqkv, dWqkv, dbqkv, s);
+  if (d == 32) return launch<32>(y, dqkv, rows, Wqkv, dWqkv, dbqkv, s);
+  return fail(SAGNN_ERR_DIM, "f16 attn_bwd_tail: d must be 32 or 64 (got %d)", d);
+}
+
+}  // namespace sagnn

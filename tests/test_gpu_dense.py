@@ -64,3 +64,34 @@ def test_attn_bwd_tail(dev, rows, d):
     torch.testing.assert_close(dW.cpu().double(), want_dW, rtol=1e-4, atol=2e-6 * float(want_dW.abs().max()) + 1e-5)
     torch.testing.assert_close(db.cpu().double(), dqkv.double().sum(0), rtol=1e-4, atol=2e-4)
     assert torch.equal(gd.cpu(), dqkv)                                     # dQKV itself is read-only
+
+
+@pytest.mark.parametrize("rows,d", [(1000, 64), (20011, 64), (777, 32)])
+def test_attn_bwd_tail_beyond_the_f16_range(dev, rows, d):
+    """The tail's products run on two-piece f16 operands. A chunk of 32 rows that holds a value beyond 65504 (here a
+    gradient of 1e6, a y of -3e5 and an isolated 2e30) takes no part in the matrix-core products: the block evaluates
+    it with fp32 fmaf chains. dy, dW and db of the flagged chunks, of their neighbours and of the rest must match."""
+    from sa_gnn_amd import _lib, ops
+    lib = _lib.load()
+    gen = torch.Generator(device="cpu").manual_seed(3 * rows + d)
+    y = torch.randn((rows, d), generator=gen)
+    dqkv = torch.randn((rows, 3 * d), generator=gen)
+    W = torch.randn((d, 3 * d), generator=gen) / d ** 0.5
+    dqkv[5, 7] = 1e6
+    y[rows // 2, 3] = -3e5
+    dqkv[rows - 1, 3 * d - 1] = 2e30
+    yd, gd, Wd = y.to(dev), dqkv.to(dev), W.to(dev)
+    dW = torch.zeros((d, 3 * d), device=dev)
+    db = torch.zeros(3 * d, device=dev)
+    ops.check(lib.sagnn_attn_bwd_tail_f32(yd.data_ptr(), gd.data_ptr(), rows, d, Wd.data_ptr(), dW.data_ptr(),
+                                          db.data_ptr(), None))
+    want_dy = dqkv.double() @ W.double().T
+    want_dW = y.double().T @ dqkv.double()
+    want_db = dqkv.double().sum(0)
+    assert torch.isfinite(yd).all() and torch.isfinite(dW).all()
+    # the huge entries dominate their own rows / columns: relative to each output's own scale
+    torch.testing.assert_close(yd.cpu().double(), want_dy, rtol=1e-4, atol=1e-5)
+    tol_w = 1e-4 * want_dW.abs() + 2e-6 * (y.double().abs().T @ dqkv.double().abs()) + 1e-5
+    assert ((dW.cpu().double() - want_dW).abs() <= tol_w).all()
+    tol_b = 1e-4 * want_db.abs() + 2e-6 * dqkv.double().abs().sum(0) + 2e-4
+    assert ((db.cpu().double() - want_db).abs() <= tol_b).all()
