@@ -421,6 +421,9 @@ def main():
                    "embed_dim": d, "gnn_layers": L, "heads": heads, "stages": a.stages,
                    "exchange": a.exchange if world > 1 else "none", "scale": a.scale, "item_zipf_s": a.zipf,
                    "launch": "hipGraph replay" if graph_mode else "eager",
+                   "fusion_gemm": {"": "f16x2 (two round-to-nearest f16 pieces, three piece products, fp32 accumulation)",
+                                   "bf16x3": "bf16x3 (LSTM: three exact bf16 pieces, six piece products)",
+                                   "f32": "f32 MFMA"}.get(os.environ.get("SAGNN_GEMM", ""), os.environ.get("SAGNN_GEMM", "")),
                    "partitioning": (f"T < world: {sh.group_size} ranks per interval, target rows split inside a group; fusion row-sharded"
                                     if split else f"interval k -> rank k mod {world}; fusion row-sharded")},
         "ms_per_step_rank0": {"median": float(np.median(step_ms)), "min": float(np.min(step_ms)), "max": float(np.max(step_ms)),
