@@ -4,21 +4,16 @@
 // i, j, f, o = split(gates); c' = c sigmoid(f + fb) + sigmoid(i) tanh(j); h' = tanh(c') sigmoid(o).
 //
 // Same decomposition as lstm_split_kernel.h (transposed product, W slices register-resident, x_t / h as
-// 16-bit images in LDS, gate math hand-interleaved with the MFMAs) with HALF the matrix-core work:
-// every fp32 operand is cut into TWO f16 pieces by round-to-nearest,
-//     v = v1 + v2 + e,   v1 = rn16(v),   v2 = rn16(4096 (v - v1)) / 4096,   |e| <= 2^-23 |v|
-// (v - v1 is exact in fp32; the residual is kept scaled by 2^12 so that it stays a normal f16 number),
-// and the product is evaluated as three piece products in two fp32 accumulators,
-//     a b ~ a1 b1  +  2^-12 (a1 b2' + a2' b1),
-// each a v_mfma_f32_16x16x32_f16. Dropped: a2 b2 <= 2^-22 |a b|. Measured against a float64 product
-// (tools/microbench/f16_split.hip, K = 128): max error 0.35 x that of an fp32 fmaf chain — the same
-// class as the six-product bf16 form, at 3/6 of its MFMAs and 2/3 of its LDS images and registers.
+// 16-bit images in LDS, gate math hand-interleaved with the MFMAs) with HALF the matrix-core work: the
+// two-piece f16 split of f16_split.h (three piece products into a head and a residual accumulator that the
+// gate math joins with one fma) instead of three bf16 pieces and six products — the same accuracy class
+// at 3/6 of the MFMAs and 2/3 of the LDS images and weight registers.
 //
 // f16 has 5 exponent bits: |v| > 65504 does not fit a piece. Small values are safe (the matrix core
 // honours f16 denormals, checked in the same microbenchmark; a denormal head only moves bits into the
 // scaled residual). LARGE ones are detected — every x / initial-h value passes through a running
 // max on its way into LDS, W when the fragments are built — and a workgroup that saw one re-evaluates
-// its 96-row tile after the fast pass with plain fp32 fmaf chains (slow_tile below), so the results
+// its 96-row tile after the fast pass with plain fp32 fmaf chains (the block after the step loop), so the results
 // are those of an fp32 evaluation for every finite input; the fast path carries two extra VALU
 // operations per 16 bytes of x for it.
 #include <type_traits>

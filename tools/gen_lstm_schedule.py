@@ -4,7 +4,8 @@ operations of one 16-row batch tile (numbered as in `gate_op` of the kernel head
 MFMAs of the next tile, and where each MFMA gap's share begins.
 
     python tools/gen_lstm_schedule.py 4 > sa-gnn_amd/csrc/lstm_f16_schedule.inc     # 4 hidden units per lane
-    python tools/gen_lstm_schedule.py 2 > sa-gnn_amd/csrc/lstm_f16w_schedule.inc    # 2 hidden units per lane
+    python tools/gen_lstm_schedule.py 2                                            # 2 hidden units per lane: the eight-waves-per-
+                                                                                    # workgroup form measured as no gain
 
 A list scheduler over the operations' dependency graph: every MFMA gap gets at most `max_trans`
 transcendentals (v_exp_f32 / v_rcp_f32: 8 issue cycles, the rest 4 — MI355X_MICROARCH.md, per-instruction
