@@ -42,11 +42,17 @@ def test_dense_tn(dev, n, din, dout):
     torch.testing.assert_close(dW.cpu().double(), 2 * want, rtol=1e-4, atol=4e-6 * scale + 1e-5)
 
 
+@pytest.mark.parametrize("engine", ["f16x2", "f32"])
 @pytest.mark.parametrize("rows,d", [(1000, 64), (31, 64), (40007, 64), (513, 32), (70001, 32)])
-def test_attn_bwd_tail(dev, rows, d):
+def test_attn_bwd_tail(dev, rows, d, engine, monkeypatch):
     """sagnn_attn_bwd_tail_f32: dy (over y), dW and db of the three dense layers in one pass over
-    dQ|dK|dV, against float64 matmuls; sizes from one ragged chunk to many chunks per block."""
+    dQ|dK|dV, against float64 matmuls; sizes from one ragged chunk to many chunks per block. Both engines:
+    the f16 matrix cores (default) and the f32-MFMA kernel of round 1 (SAGNN_GEMM=f32)."""
     from sa_gnn_amd import _lib, ops
+    if engine == "f32":
+        monkeypatch.setenv("SAGNN_GEMM", "f32")
+    else:
+        monkeypatch.delenv("SAGNN_GEMM", raising=False)
     lib = _lib.load()
     gen = torch.Generator(device="cpu").manual_seed(rows + d)
     y = torch.randn((rows, d), generator=gen)
