@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SAGNN_VERSION 10200 /* 1.2.0 */
+#define SAGNN_VERSION 10300 /* 1.3.0 */
 
 enum {
   SAGNN_OK = 0,
@@ -46,6 +46,19 @@ enum {
 };
 
 int sagnn_version(void);
+
+/* Arithmetic engine of the GEMM-shaped fusion stages (LSTM gate product, the three dense layers of the
+ * attention, their backward products), selected PER CALLING THREAD — there is no environment switch and no
+ * process-wide state: a thread that never calls sagnn_set_engine runs SAGNN_ENGINE_F16X2.
+ *   SAGNN_ENGINE_F16X2  the default: 16-bit matrix cores over two-piece split fp32 operands (see ARITHMETIC below)
+ *   SAGNN_ENGINE_F32    v_mfma_f32_32x32x2_f32 kernels: an fp32 fmaf chain bit for bit (d in {32, 64}; the exact-fp32
+ *                       reference the default engine is measured against)
+ *   SAGNN_ENGINE_VALU   the plain VALU formulations (any d)
+ * sagnn_set_engine returns SAGNN_OK or SAGNN_ERR_ARG; sagnn_get_engine the calling thread's engine. The SpMM is
+ * plain fp32 under every engine. */
+enum { SAGNN_ENGINE_F16X2 = 0, SAGNN_ENGINE_F32 = 1, SAGNN_ENGINE_VALU = 2 };
+int sagnn_set_engine(int engine);
+int sagnn_get_engine(void);
 
 /* Copies the calling thread's last error text (NUL-terminated, truncated to cap) and
  * returns its full length. */
@@ -239,15 +252,22 @@ int sagnn_gnn_interval_bwd_f32(const sagnn_spmm_plan* plan_user, const sagnn_spm
  *   normalised in place; only out [n, d] is a result.
  *
  * ARITHMETIC of the GEMM-shaped stages (the gate product [x_t | h] W and the three dense layers)
- *   for d in {32, 64, 128}, 16 heads: fp32 in, fp32 out, evaluated on the 16-bit matrix cores over
- *   SPLIT operands: two round-to-nearest f16 pieces per value (v = v1 + v2'/4096, representation error
- *   <= 2^-23 |v|), three piece products, fp32 accumulation; a value beyond the f16 range (|v| > 65504)
- *   is detected in the kernel and the tile that holds it is re-evaluated with fp32 fmaf chains, so every
- *   finite input gets an fp32-grade result: as close to the float64 product as an fp32 fmaf chain, not
- *   bit-identical to one. Environment (A/B only): SAGNN_GEMM=bf16x3 selects, for the d = 32 / 64 LSTM,
- *   three exactly cut bf16 pieces and the six largest piece products (dropped < 2^-20 |a b|), SAGNN_GEMM=f32 the v_mfma_f32_32x32x2_f32 kernels (an fmaf chain
- *   bit for bit; d = 32 / 64), SAGNN_FUSION=valu the VALU formulations. Results are deterministic run to
- *   run in every mode.
+ *   for d in {32, 64, 128}, 16 heads, under the default engine: fp32 in, fp32 out, evaluated on the 16-bit
+ *   matrix cores over SPLIT operands: two round-to-nearest f16 pieces per value (v = v1 + v2'/4096), three piece
+ *   products, fp32 accumulation. The split represents v to 2^-23 |v| inside a window — |v| < 32768 at the top, and an
+ *   ABSOLUTE floor of 2^-37 at the bottom — so what is guaranteed is:
+ *     - every operand goes through a range check on its way to the matrix cores: a tile that holds |v| >= 32768, or
+ *       an aligned 4-element segment that is non-zero but below 2^-18 as a whole (an input row of 1e-9), is
+ *       re-evaluated in the kernel with fp32 fmaf chains. Such inputs get exactly an fp32 evaluation.
+ *     - on the fast path each operand element is within max(2^-23 |v|, 2^-37) of its fp32 value, i.e. within
+ *       2^-19 of its segment's largest element at worst and 2^-23 for segments above 2^-14 (every layer-normed row,
+ *       every embedding sum): as close to the float64 product as an fp32 fmaf chain for such rows, not bit-identical
+ *       to one.
+ *     - gradients have no natural scale, so the attention-backward tail (sagnn_attn_bwd_tail_f32) scales every row
+ *       of dQ|dK|dV by an exact power of two before the split: dy is accurate per ROW (relative to that row's own
+ *       largest gradient, from 1e-38 to 1e38), dW / db relative to the sum of the magnitudes of their terms.
+ *   sagnn_set_engine(SAGNN_ENGINE_F32) selects the exact-fp32 kernels instead. Results are deterministic run to run
+ *   under every engine.
  * -------------------------------------------------------------------------------- */
 int sagnn_lstm_fwd_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
                        const float* b, float forget_bias, const float* drop_scale, float* h,
@@ -271,8 +291,8 @@ int sagnn_mhsa_mean_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, i
 /* "Wide" attention for any d that is a multiple of 32 (e.g. the MovieLens configuration, d = 128,
  * whose three [d, d] weights and Q|K|V tiles do not fit LDS together): Q|K|V by MFMA products
  * (sagnn_dense_nn_f32's kernel) into caller scratch [n, t, 3d], then a per-node attention kernel.
- * sagnn_interval_fusion_f32 and the Python wrappers route here automatically; the LSTM keeps its
- * VALU form for such d. */
+ * sagnn_interval_fusion_f32 and the Python wrappers route here for d other than 32 / 64 / 128 (d = 128, 16 heads
+ * runs the split-operand kernels: attention over two column halves, the LSTM as one launch per step). */
 size_t sagnn_mhsa_wide_workspace_bytes(int64_t n, int t, int d);
 int sagnn_mhsa_mean_wide_f32(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
                              const float* Wq, const float* bq, const float* Wk, const float* bk, const float* Wv,
@@ -298,7 +318,9 @@ size_t sagnn_interval_fusion_workspace_bytes(int64_t n, int t, int d);
 /* ------------------------------------------------------------------------------------
  * Backward of the interval fusion: the gradients tf.gradients derives for
  * model.py:135-155. The host (sa-gnn_amd/autograd.py) sequences these entries with the dense
- * products below; d in {32, 64}, d_k a power of two.
+ * products below. Any d that is a multiple of 32 trains through the per-step entries and the dense products
+ * (d = 128 is checked against the float64 oracle); the fused entries — attention-backward front and tail, the
+ * one-launch BPTT — say which d they cover through their *_supported queries. d_k a power of two.
  *
  * sagnn_lstm_fwd_train_f32 — sagnn_lstm_fwd_f32 that also stores the gate activations
  *   gates [n, t, 4d] = sigmoid(i) | tanh(j) | sigmoid(f + forget_bias) | sigmoid(o) and the cell

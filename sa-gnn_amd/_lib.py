@@ -40,6 +40,8 @@ class PlanInfo(ctypes.Structure):
 # name -> (restype, argtypes); must list every symbol include/sagnn.h declares
 SIGNATURES = {
     "sagnn_version": (c_int, []),
+    "sagnn_set_engine": (c_int, [c_int]),
+    "sagnn_get_engine": (c_int, []),
     "sagnn_last_error": (c_size_t, [c_char_p, c_size_t]),
     "sagnn_profile_enable": (c_int, [c_int]),
     "sagnn_profile_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, POINTER(c_int)]),

@@ -3,11 +3,14 @@
 libsagnn.so; torch only carries the graph."""
 from __future__ import annotations
 
-import os
-
 import torch
 
 from . import ops
+
+# Host-side A/B switches (tests flip them): False routes the backward through the per-step / per-product entries
+# that the fused entries (attention-backward front + tail, one-launch BPTT) replaced.
+FUSED_ATTN_BWD = True
+FUSED_BPTT = True
 
 
 class GnnIntervalFn(torch.autograd.Function):
@@ -192,7 +195,7 @@ class IntervalFusionFn(torch.autograd.Function):
         # ---- recompute y and Q|K|V, attention backward -> dQ|dK|dV -----------------------------
         h_emit = h if drop is None else ops.mul(h, drop.contiguous())
         Wqkv = torch.cat([Wq, Wk, Wv], dim=1).detach().contiguous()                      # [d, 3d]
-        if lib.sagnn_attn_bwd_front_supported(d, t, heads) and os.environ.get("SAGNN_ATTN_BWD", "") != "steps":
+        if lib.sagnn_attn_bwd_front_supported(d, t, heads) and FUSED_ATTN_BWD:
             y2, qkv = _attn_bwd_front(h_emit, ln_gamma.detach(), ln_beta.detach(), Wq, bq, Wk, bk, Wv, bv, heads, g_out)
         else:
             y = ops.layernorm_td(h_emit, ln_gamma.detach(), ln_beta.detach())            # [n, t, d]
@@ -202,7 +205,7 @@ class IntervalFusionFn(torch.autograd.Function):
             ops.check(lib.sagnn_attn_bwd_f32(qkv.data_ptr(), g_out.data_ptr(), d, n, t, d, heads, st))
         dWqkv = torch.zeros((d, 3 * d), dtype=torch.float32, device=dev)
         dbqkv = torch.zeros(3 * d, dtype=torch.float32, device=dev)
-        if lib.sagnn_attn_bwd_tail_supported(d) and os.environ.get("SAGNN_ATTN_BWD", "") != "steps":
+        if lib.sagnn_attn_bwd_tail_supported(d) and FUSED_ATTN_BWD:
             # dW += y^T dQKV, db += colsum dQKV and dy = dQKV W^T (over y) in one pass over dQKV
             ops.check(lib.sagnn_attn_bwd_tail_f32(y2.data_ptr(), qkv.data_ptr(), n * t, d, Wqkv.data_ptr(),
                                                   dWqkv.data_ptr(), dbqkv.data_ptr(), st))
@@ -218,7 +221,7 @@ class IntervalFusionFn(torch.autograd.Function):
                                                  ops._vec("gamma", ln_gamma.detach(), d), 1e-12, dh.data_ptr(),
                                                  t * d, dgamma.data_ptr(), dbeta.data_ptr(), st))
         # ---- BPTT ----------------------------------------------------------------------------------
-        if lib.sagnn_lstm_bwd_supported(d) and os.environ.get("SAGNN_BPTT", "") != "steps":
+        if lib.sagnn_lstm_bwd_supported(d) and FUSED_BPTT:
             dx, dW, db = lstm_bwd(x, h, gates, cell, dh, drop, lstm_W.detach())
             return (dx, dW, db, dgamma, dbeta) + _split_qkv_grads(dWqkv, dbqkv, d) + (None, None)
         Wd = lstm_W.detach()
@@ -265,7 +268,7 @@ def _mhsa_mean_backward(y, Wq, bq, Wk, bk, Wv, bv, heads, g_out):
     Wqkv = torch.cat([Wq, Wk, Wv], dim=1).detach().contiguous()
     bqkv = torch.cat([bq, bk, bv]).detach().contiguous()
     y2 = y.reshape(n * t, d)
-    if lib.sagnn_attn_bwd_front_supported(d, t, heads) and os.environ.get("SAGNN_ATTN_BWD", "") != "steps":
+    if lib.sagnn_attn_bwd_front_supported(d, t, heads) and FUSED_ATTN_BWD:
         _, qkv = _attn_bwd_front(y.contiguous(), None, None, Wq, bq, Wk, bk, Wv, bv, heads, g_out.contiguous())
     else:
         qkv = ops.dense_nn(y2, Wqkv, bqkv)

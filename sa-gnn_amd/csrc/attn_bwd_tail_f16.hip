@@ -16,8 +16,9 @@
 // (ds_read_b64_tr_b16: a 16-lane group fetches a 4-row x 16-column block and each lane receives one column —
 // no second copy, no cross-lane traffic). dW's 6 (3 at D = 32) head and residual accumulator tiles per wave live
 // across all chunks of the block and are flushed once with float atomics; db rides on the same product as a tile row of
-// ones. A chunk holding a value beyond the f16 range (|v| > 65504) takes no part in the MFMAs: the block evaluates
-// it with fp32 fmaf chains instead (a W holding one: every chunk).
+// row factors. dQKV is a gradient of arbitrary scale: its rows enter the images at exact power-of-two scales (GRADIENT
+// RANGE below), so dy is accurate per row and dW / db relative to the sum of their terms' magnitudes at any scale.
+// A chunk the window cannot hold takes no part in the MFMAs: the block evaluates it with fp32 fmaf chains (a W out of range: every chunk).
 #include "common.h"
 #include "f16_split.h"
 
@@ -62,35 +63,79 @@ __host__ __device__ constexpr int bias_slot(int b, int nmt, int nbw) {
   return b - first;
 }
 
+// max over the lanes of a row group (8 or 16 consecutive lanes) of a non-negative int, by DPP butterflies
+template <int CTRL>
+__device__ __forceinline__ int dpp_max(int v) {
+  const int o = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+  return o > v ? o : v;
+}
+template <int LANES>
+__device__ __forceinline__ int group_max(int v) {
+  v = dpp_max<0xB1>(v);                            // quad_perm [1,0,3,2]
+  v = dpp_max<0x4E>(v);                            // quad_perm [2,3,0,1]
+  v = dpp_max<0x141>(v);                           // row_half_mirror: the other quad of the 8
+  if constexpr (LANES == 16) v = dpp_max<0x140>(v);   // row_mirror: the other half of the 16
+  return v;
+}
+__device__ __forceinline__ float pow2_field(int field) {   // 2^(field - 127), 0 for field <= 0
+  return __builtin_bit_cast(float, (field < 0 ? 0 : field > 254 ? 254 : field) << 23);
+}
+
+// GRADIENT RANGE. dQKV is a gradient: its scale is arbitrary (an SSL-only row carries 1e-9, a hinge row 1e-3) and
+// every row matters on its own, because dy feeds per-row chains (layer-norm backward, BPTT, embedding rows) and
+// Adam is scale-free per element. The two-piece f16 split has an absolute floor of 2^-37 (f16_split.h), so the rows
+// are brought into its window by EXACT powers of two:
+//   * row r of the dQKV images holds dQKV[r] 2^(127 - k_r), k_r = the biased fp32 exponent of the row's max |.|
+//     (clamped to 1 .. 253): the row's max is in [1, 2) (below 4 at the clamp). dy[r] is descaled by 2^(k_r - 127)
+//     at its store — per-row accuracy is that of rows of magnitude one, at any scale.
+//   * dW = sum_r y[r]^T dQKV[r] needs one scale for all rows, so row r of the y image holds y[r] 2^(k_r - E + kUp):
+//     every term arrives as y dQKV 2^(127 - E + kUp); E follows the largest k the block has met (its accumulators
+//     are rescaled when E grows, a block-uniform event) and the flush undoes the factor. A row 2^delta below E keeps
+//     its y to max(2^-23, 2^(delta - 43) / |y|): fp32-grade down to a million times below the largest row, degrading
+//     from there — where such a row's terms are 2^-delta of the largest row's. db rides on the same product
+//     with a "ones" operand that carries the row factor (a power of two: exact in two f16 pieces down to delta = 42).
+//   * E for the chunk being committed is known one chunk LATE (row exponents meet in an LDS max that the next
+//     barrier publishes), so a row may exceed it: the scaled y row then reaches 32768 (roughly: the row is > 100
+//     times larger than anything before it), its chunk is flagged and evaluated with fp32 fmaf chains — as are
+//     chunks holding a non-finite gradient, a y segment below 2^-14, or a W out of range. One chunk raises E by at
+//     most 2^kJump (the first chunk: at most that much above its 4th largest row), so an isolated absurd entry
+//     (2e30 in a field of ones) goes through the fp32 path without wiping out the rows after it.
+constexpr int kUp = 6, kJump = 16;
+constexpr float kUpInv = 1.f / 64.f;   // 2^-kUp
+
 template <int D>
 __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd_tail_f16_kernel(float* __restrict__ y, const float* __restrict__ dqkv,
                                                                       int64_t rows, const float* __restrict__ W,
                                                                       float* __restrict__ dW, float* __restrict__ db,
                                                                       int64_t n_chunks) {
   constexpr int Q3 = 3 * D;              // dQKV columns
-  constexpr int S4 = D;                  // float4 slots per staged row: y | dQKV = 4 D floats
   constexpr int SUB = kRows * D * 2;     // bytes of one [32][D] f16 sub-image
   constexpr int PIECE = 4 * SUB;         // y | dQ | dK | dV
   constexpr int BUF = 2 * PIECE;         // heads, scaled residuals
   constexpr int NWV = D / 8;             // waves per block: 8 at D = 64 (two per SIMD), 4 at D = 32 (two blocks per CU)
   constexpr int kBlock = 64 * NWV;
-  constexpr int NV = kRows * S4 / kBlock;   // float4 per thread and chunk (4)
+  constexpr int LPRW = D / 4;            // lanes per staged row: lane j holds float4 j of the row's y, dQ, dK and dV
   constexpr int NMT = D / 16, NNT = Q3 / 16;   // dW: NMT x NNT tiles of 16 x 16
   constexpr int MB = 1;                  // dW tile rows per wave ...
   constexpr int NBW = NMT * NNT / NWV;   // ... and tile columns per wave (6 / 3)
   constexpr int KS1 = Q3 / 32;           // k-steps of dy (6 / 3)
   constexpr int NT1 = D / 16;            // column tiles of dy (4 / 2)
   constexpr int M1 = 1;                  // dy tiles per wave: (row tile wave / NT1, column tile wave % NT1)
-  static_assert(NV * kBlock == kRows * S4 && 2 * NT1 == NWV && NNT % (NWV / NMT) == 0, "unsupported D");
+  static_assert(kBlock == kRows * LPRW && 2 * NT1 == NWV && NNT % (NWV / NMT) == 0, "unsupported D");
 
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  int* const flags = reinterpret_cast<int*>(lds + 2 * BUF);   // [0], [1]: chunk number (+1) in that buffer if it is out of range; [2]: W is
+  int* const flags = reinterpret_cast<int*>(lds + 2 * BUF);   // [0], [1]: chunk number (+1) in that buffer if it takes the fp32 path; [2]: W does
+  int* const emax = flags + 4;                                 // [3]: largest row exponent of a chunk, rotating (see the loop)
+  float* const inv = reinterpret_cast<float*>(flags + 8);      // [2][32]: 2^(k_r - 127), the descale of dy's rows
+  char* const ones = reinterpret_cast<char*>(inv + 2 * kRows); // [2][2][32] f16: head and scaled residual of 2^(k_r - E + kUp)
+  int* const ktab = reinterpret_cast<int*>(ones + 4 * kRows * 2);  // [32]: the first chunk's row exponents
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, kq = lane >> 4;
+  const int sr = tid / LPRW, sc = tid % LPRW;   // staging: my row of the chunk, my float4 of each of its four parts
   float k4096 = 4096.f;
   asm volatile("" : "+v"(k4096));
-  if (tid < 3) flags[tid] = 0;
+  if (tid < 8) flags[tid] = 0;
   __syncthreads();
 
   // ---- dy: this wave's column tile of W^T as B fragments, resident: B[k = o][j] = Wqkv[16 nt1 + j][o]
@@ -98,7 +143,7 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
   const int mt1_0 = wave / NT1;
   i32x4 wf[KS1][2];
   {
-    float wmax = 0.f;
+    RangeTrack wr = range_init();
     const float* wrow = W + (size_t)(16 * nt1 + m) * Q3 + 8 * kq;
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
@@ -109,10 +154,11 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
         const int hd = head2(wv[2 * e], wv[2 * e + 1]);
         wf[ks][0][e] = hd;
         wf[ks][1][e] = tail2(hd, wv[2 * e], wv[2 * e + 1], k4096);
-        wmax = max3abs(wmax, wv[2 * e], wv[2 * e + 1]);
       }
+      range_seg4(wr, a.x, a.y, a.z, a.w);
+      range_seg4(wr, b.x, b.y, b.z, b.w);
     }
-    if (wmax > kF16Max) flags[2] = 1;   // read after the barriers below
+    if (range_bad(wr)) flags[2] = 1;   // read after the barriers below
   }
   // ---- dW: my tiles (wm * MB + a, wn * NBW + b), head and residual accumulators
   const int wm = wave % NMT, wn = wave / NMT;
@@ -123,49 +169,83 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
     for (int b = 0; b < NBW; ++b) hiw[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}, low[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 hib[2], lob[2];                                  // db tiles of the columns I own (at most two)
   hib[0] = hib[1] = lob[0] = lob[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const i32x4 ones = {0x3C003C00, 0x3C003C00, 0x3C003C00, 0x3C003C00};   // f16 1.0 in every A element: head 1, residual 0
 
-  float4 stage[NV];
+  float4 stage[4];                                       // y | dQ | dK | dV: my float4 of my row
   auto fetch = [&](int64_t ch) {
     const int64_t row0 = ch * kRows;
     const int last = (int)(rows - 1 - row0 < kRows - 1 ? rows - 1 - row0 : kRows - 1);  // uniform
-    const float* ybase = y + row0 * D;
-    const float* gbase = dqkv + row0 * Q3;
+    const uint32_t rc = sr < last ? sr : last;           // rows past the end read the last row, zeroed below
+    const bool ok = sr <= last;
+    const float* const yp = y + row0 * D + (rc * D + 4 * sc);
+    const float* const gp = dqkv + row0 * Q3 + (rc * Q3 + 4 * sc);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int i = tid + v * kBlock;
-      const int r = i / S4, s = i - r * S4;
-      const uint32_t rc = r < last ? r : last;          // rows past the end read the last row, zeroed below
-      const float4 val = s < D / 4 ? *reinterpret_cast<const float4*>(ybase + (rc * D + 4 * s))
-                                   : *reinterpret_cast<const float4*>(gbase + (rc * Q3 + 4 * (s - D / 4)));
-      const bool ok = r <= last;
+    for (int v = 0; v < 4; ++v) {
+      const float4 val = *reinterpret_cast<const float4*>(v == 0 ? yp : gp + (v - 1) * D);
       stage[v] = make_float4(ok ? val.x : 0.f, ok ? val.y : 0.f, ok ? val.z : 0.f, ok ? val.w : 0.f);
     }
   };
-  // split the staged rows into buffer `b`; `id` = chunk number + 1 marks the buffer if a value does not fit
-  auto commit = [&](int b, int id) {
+  // biased exponent of the largest |dQKV| of my staged row (all lanes of the row agree)
+  auto row_exponent = [&]() -> int {
+    float mx = max3abs(max3abs(0.f, stage[1].x, stage[1].y), stage[1].z, stage[1].w);
+    mx = max3abs(max3abs(mx, stage[2].x, stage[2].y), stage[2].z, stage[2].w);
+    mx = max3abs(max3abs(mx, stage[3].x, stage[3].y), stage[3].z, stage[3].w);
+    return group_max<LPRW>(__builtin_bit_cast(int, mx)) >> 23;
+  };
+  // split the staged row into buffer `b` at the scales described above; `id` = chunk number + 1 marks the buffer for the fp32 path
+  auto commit = [&](int b, int id, int e, int E) {
     char* const buf = lds + b * BUF;
-    float vmax = 0.f;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const int i = tid + v * kBlock;
-      const int r = i / S4, s = i - r * S4;
-      const int sub = s / (D / 4), c4 = s - sub * (D / 4);
-      const float4 x = stage[v];
-      const int p0 = head2(x.x, x.y), p1 = head2(x.z, x.w);
-      char* const dst = buf + sub * SUB + img_off<D>(r, c4 >> 1) + (c4 & 1) * 8;
+    const int k = e > 253 ? 253 : e < 1 ? 1 : e;
+    const float s = pow2_field(254 - k);               // dQKV row scale
+    const float f = pow2_field(127 + k - E + kUp);     // y row scale
+    char* const dst = buf + img_off<D>(sr, sc >> 1) + (sc & 1) * 8;
+    const float4 yr = stage[0];
+    const float4 yv = make_float4(yr.x * f, yr.y * f, yr.z * f, yr.w * f);
+    {
+      const int p0 = head2(yv.x, yv.y), p1 = head2(yv.z, yv.w);
       *reinterpret_cast<i32x2*>(dst) = i32x2{p0, p1};
-      *reinterpret_cast<i32x2*>(dst + PIECE) = i32x2{tail2(p0, x.x, x.y, k4096), tail2(p1, x.z, x.w, k4096)};
-      vmax = max3abs(max3abs(vmax, x.x, x.y), x.z, x.w);
+      *reinterpret_cast<i32x2*>(dst + PIECE) = i32x2{tail2(p0, yv.x, yv.y, k4096), tail2(p1, yv.z, yv.w, k4096)};
     }
-    if (vmax > kF16Max) flags[b] = id;
+#pragma unroll
+    for (int v = 1; v < 4; ++v) {
+      int h0, t0, h1, t1;
+      split2_scaled(stage[v].x, stage[v].y, s, k4096, h0, t0);
+      split2_scaled(stage[v].z, stage[v].w, s, k4096, h1, t1);
+      *reinterpret_cast<i32x2*>(dst + v * SUB) = i32x2{h0, h1};
+      *reinterpret_cast<i32x2*>(dst + v * SUB + PIECE) = i32x2{t0, t1};
+    }
+    if (sc == 0) {
+      inv[b * kRows + sr] = pow2_field(k);
+      const int oh = head2(f, 0.f);
+      const int ot = tail2(oh, f, 0.f, k4096);
+      *reinterpret_cast<short*>(ones + (b * 2 + 0) * (kRows * 2) + sr * 2) = (short)oh;
+      *reinterpret_cast<short*>(ones + (b * 2 + 1) * (kRows * 2) + sr * 2) = (short)ot;
+    }
+    const float ys = maxabs_acc(maxabs3(yr.x, yr.y, yr.z), yr.w);       // the raw segment: small as a whole?
+    const float yt = maxabs_acc(maxabs3(yv.x, yv.y, yv.z), yv.w);       // the scaled one: does it fit?
+    if (yt >= kF16Lim || (ys > 0.f && ys < 6.103515625e-05f) || e == 255) flags[b] = id;
   };
 
   int64_t ch = blockIdx.x;
-  int cur = 0;
+  int cur = 0, slot = 0;   // buffer of chunk ch; emax slot its rows posted to
+  int e_run = 1;           // E the y rows of chunk ch were scaled against
+  int e_acc = 0;           // E the accumulators are at (0: nothing accumulated yet)
   if (ch < n_chunks) {
     fetch(ch);
-    commit(0, (int)(ch + 1));
+    const int e = row_exponent();
+    if (sc == 0) ktab[sr] = e > 253 ? 253 : e < 1 ? 1 : e;
+    __syncthreads();
+    // the first chunk is scaled against its own largest row, but no more than 2^kJump above its 4th largest
+    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+    for (int j = 0; j < kRows; ++j) {
+      int v = ktab[j], a;
+      a = t0 > v ? t0 : v, v = t0 > v ? v : t0, t0 = a;
+      a = t1 > v ? t1 : v, v = t1 > v ? v : t1, t1 = a;
+      a = t2 > v ? t2 : v, v = t2 > v ? v : t2, t2 = a;
+      t3 = t3 > v ? t3 : v;
+    }
+    e_run = t0 < t3 + kJump ? t0 : t3 + kJump;
+    commit(0, (int)(ch + 1), e, e_run);
   }
   __syncthreads();
   for (; ch < n_chunks; ch += gridDim.x) {
@@ -179,6 +259,17 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
     asm volatile("" : "+v"(lane_), "+v"(m_), "+v"(kq_));
 
     if (!slow) {
+      if (e_acc != e_run) {   // E grew (block-uniform, a handful of times per block): the accumulators follow
+        if (e_acc != 0) {
+          const float g = pow2_field(127 + e_acc - e_run);
+#pragma unroll
+          for (int a = 0; a < MB; ++a)
+#pragma unroll
+            for (int b = 0; b < NBW; ++b) hiw[a][b] *= g, low[a][b] *= g;
+          hib[0] *= g, hib[1] *= g, lob[0] *= g, lob[1] *= g;
+        }
+        e_acc = e_run;
+      }
       // ---- dW tiles += y^T dQKV (K = the chunk's 32 rows): both operands read transposed
       {
         i32x4 a1[MB], a2[MB];
@@ -187,6 +278,9 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
           a1[a] = read_tr<D>(buf, wm * MB + a, lane_);
           a2[a] = read_tr<D>(buf + PIECE, wm * MB + a, lane_);
         }
+        // the rows' factors as an A operand whose 16 M rows are all equal: A[.][k = 8 kq + j] = factor of row 8 kq + j
+        const i32x4 o1 = *reinterpret_cast<const i32x4*>(ones + (cur * 2 + 0) * (kRows * 2) + 16 * kq_);
+        const i32x4 o2 = *reinterpret_cast<const i32x4*>(ones + (cur * 2 + 1) * (kRows * 2) + 16 * kq_);
 #pragma unroll
         for (int b = 0; b < NBW; ++b) {
           const int col = 16 * (wn * NBW + b);              // dQKV column of the tile
@@ -201,8 +295,9 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
           }
           if (bias_owner(b, NMT, NBW) == wm) {   // wave-uniform
             const int sl = bias_slot(b, NMT, NBW);   // a constant once the loop is unrolled
-            lob[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ones), __builtin_bit_cast(f16x8, b2), lob[sl], 0, 0, 0);
-            hib[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ones), __builtin_bit_cast(f16x8, b1), hib[sl], 0, 0, 0);
+            lob[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, o2), __builtin_bit_cast(f16x8, b1), lob[sl], 0, 0, 0);
+            lob[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, o1), __builtin_bit_cast(f16x8, b2), lob[sl], 0, 0, 0);
+            hib[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, o1), __builtin_bit_cast(f16x8, b1), hib[sl], 0, 0, 0);
           }
           __builtin_amdgcn_sched_barrier(0);   // one tile column's operands in flight at a time
         }
@@ -225,14 +320,15 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
           hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(g1, __builtin_bit_cast(f16x8, wf[ks][0]), hi, 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
         }
-        // C layout: lane (n = lane & 15, mq = lane >> 4) holds rows 16 mt + 4 mq + r of column 16 nt1 + n
+        // C layout: lane (n = lane & 15, mq = lane >> 4) holds rows 16 mt + 4 mq + r of column 16 nt1 + n; each row leaves at its own scale
+        const f32x4 iv = *reinterpret_cast<const f32x4*>(inv + cur * kRows + 16 * mt + 4 * kq_);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, fmaf(lo[r], kLoInv, hi[r])), rs,
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, fmaf(lo[r], kLoInv, hi[r]) * iv[r]), rs,
                                                 ((16 * mt + 4 * kq_ + r) * D + 16 * nt1 + m_) * 4, 0, 0);
       }
     } else {
-      // ---- a value beyond the f16 range in this chunk (or in W): fp32 fmaf chains. dW first (it reads y), then dy.
+      // ---- this chunk (or W) is outside the window: fp32 fmaf chains. dW first (it reads y), then dy.
       for (int idx = tid; idx < D * Q3; idx += kBlock) {
         const int i = idx / Q3, o = idx - i * Q3;
         float acc = 0.f;
@@ -252,12 +348,28 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
         y[(row0 + r) * D + i] = acc;
       }
     }
-    if (nxt < n_chunks) commit(cur ^ 1, (int)(nxt + 1));
+    int e_next = e_run;
+    const int nslot = slot == 2 ? 0 : slot + 1;
+    if (nxt < n_chunks) {
+      const int ec = emax[slot];                        // chunk ch's own rows: complete since the barrier that closed its commit
+      e_next = ec > e_run ? ec : e_run;
+      const int e = row_exponent();
+      if (sc == 0) {                                    // what chunk nxt's rows ask of the chunk after it
+        const int k = e > 253 ? 253 : e < 1 ? 1 : e;
+        atomicMax(emax + nslot, k < e_next + kJump ? k : e_next + kJump);
+      }
+      commit(cur ^ 1, (int)(nxt + 1), e, e_next);
+    }
+    if (tid == 0) emax[nslot == 2 ? 0 : nslot + 1] = 0;   // last read one iteration ago, next posted to one iteration ahead
     __syncthreads();  // next buffer complete and marked; this one free next time round
     cur ^= 1;
+    slot = nslot;
+    e_run = e_next;
   }
 
-  // ---- flush ------------------------------------------------------------------------------------------
+  // ---- flush: the accumulators hold the sums times 2^(127 - e_acc + kUp) --------------------------------------
+  if (e_acc == 0) return;   // nothing went through the matrix cores
+  const float u1 = pow2_field(e_acc), u2 = kUpInv;
 #pragma unroll
   for (int a = 0; a < MB; ++a)
 #pragma unroll
@@ -265,20 +377,20 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
       const int mt = wm * MB + a, nt = wn * NBW + b;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        atomicAdd(dW + (size_t)(16 * mt + 4 * kq + r) * Q3 + 16 * nt + m, fmaf(low[a][b][r], kLoInv, hiw[a][b][r]));
+        atomicAdd(dW + (size_t)(16 * mt + 4 * kq + r) * Q3 + 16 * nt + m, fmaf(low[a][b][r], kLoInv, hiw[a][b][r]) * u1 * u2);
     }
 #pragma unroll
   for (int b = 0; b < NBW; ++b)
     if (bias_owner(b, NMT, NBW) == wm && kq == 0) {   // every C row of a ones tile holds the column sums: row 0 speaks
       const int sl = bias_slot(b, NMT, NBW);
       const float v0 = fmaf(sl == 0 ? lob[0][0] : lob[1][0], kLoInv, sl == 0 ? hib[0][0] : hib[1][0]);
-      atomicAdd(db + 16 * (wn * NBW + b) + m, v0);
+      atomicAdd(db + 16 * (wn * NBW + b) + m, v0 * u1 * u2);
     }
 }
 
 template <int D>
 int launch(float* y, const float* dqkv, int64_t rows, const float* W, float* dW, float* db, hipStream_t s) {
-  const size_t lds = (size_t)2 * 2 * 4 * kRows * D * 2 + 16;   // 64 KB at D = 64: two blocks per CU
+  const size_t lds = (size_t)2 * 2 * 4 * kRows * D * 2 + 32 + 2 * kRows * 4 + 4 * kRows * 2 + kRows * 4;   // 64 KB of images at D = 64 + flags, row scales
   if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_tail_f16_kernel<D>), lds)) return rc;
   const int64_t n_chunks = (rows + kRows - 1) / kRows;
   const int64_t want = (D == 64 ? 1 : 2) * (int64_t)sagnn::cu_count_current();

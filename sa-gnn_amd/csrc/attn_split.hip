@@ -22,8 +22,9 @@
 //     / T — one multiply-add per (query, key) pair instead of d_k. Keys and values are taken in chunks of
 //     <= 8, the partial results of the LP lanes meet through the table, and the d_k outputs leave as one
 //     vector store.
-//   A y or W value beyond the f16 range (|v| > 65504: no sane layer norm produces one) makes the workgroup
-//     redo that tile's Q|K|V records with fp32 fmaf chains (slow_records).
+//   A y or W value outside the window of the split (f16_split.h, RANGE: |v| >= 32768, or a 4-element segment that is
+//     non-zero but below 2^-18 as a whole — the normalised rows of an input of 1e-12) makes the workgroup redo that
+//     tile's Q|K|V records with fp32 fmaf chains (slow_records).
 #include "common.h"
 #include "f16_split.h"
 
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
   char* const QKV = lds + 2 * PLANE;                        // NW tables
   float2* const rstat = reinterpret_cast<float2*>(QKV + NW * QKVW);   // [64] (mean_r, M2_r)
   float2* const nstat = rstat + kRows;                      // [NB] (mean, rstd)
-  int* const flags = reinterpret_cast<int*>(nstat + NB);    // [0], [1]: |y| beyond the f16 range in the tile of that parity; [2]: in W
+  int* const flags = reinterpret_cast<int*>(nstat + NB);    // [0], [1]: a y outside the split's window in the tile of that parity; [2]: a W
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, q = lane >> 4;
@@ -130,17 +131,16 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
   i32x4 wf[3][KS][2];
   {
     const float* const Ws[3] = {Wq, Wk, Wv};
-    float wmax = 0.f;
+    RangeTrack wr = range_init();
 #pragma unroll
     for (int mat = 0; mat < 3; ++mat)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         float wv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          wv[j] = Ws[mat][(size_t)(32 * ks + 8 * q + j) * D + cbase + m] * (mat == 0 ? qscale : 1.f);
-          wmax = __builtin_fmaxf(wmax, __builtin_fabsf(wv[j]));
-        }
+        for (int j = 0; j < 8; ++j) wv[j] = Ws[mat][(size_t)(32 * ks + 8 * q + j) * D + cbase + m] * (mat == 0 ? qscale : 1.f);
+        range_seg4(wr, wv[0], wv[1], wv[2], wv[3]);
+        range_seg4(wr, wv[4], wv[5], wv[6], wv[7]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int hd = head2(wv[2 * e], wv[2 * e + 1]);
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
           wf[mat][ks][1][e] = tail2(hd, wv[2 * e], wv[2 * e + 1], k4096);
         }
       }
-    if (wmax > kF16Max) flags[2] = 1;     // ordered before its first reader by the tile loop's barriers
+    if (range_bad(wr)) flags[2] = 1;      // ordered before its first reader by the tile loop's barriers
   }
   f32x4 bias3[3];
 #pragma unroll
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
       lds_barrier();
     }
     // ---- normalise, split into f16 pieces, store the two images
-    float ymax = 0.f;
+    RangeTrack yr = range_init();
 #pragma unroll
     for (int p = 0; p < NFILL; ++p) {
       const int r = p * RPP + fr_;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
         y.z = xr[p].z * iz + (b4.z - st.x * iz);
         y.w = xr[p].w * iw + (b4.w - st.x * iw);
       }
-      ymax = max3abs(max3abs(ymax, y.x, y.y), y.z, y.w);
+      range_seg4(yr, y.x, y.y, y.z, y.w);
       if constexpr (BWD) {
         if (y_out && r < ROWS && node0 + r / T < n) *reinterpret_cast<float4*>(y_out + (node0 * T + r) * D + fc4_) = y;
       }
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
     }
     fetch_tile(tile + gridDim.x);   // next tile's rows, in flight under this tile's products and attention
     lds_barrier();
-    if (ymax > kF16Max) flags[par] = 1;   // after the barrier that follows tid 0's reset; read after the next one
+    if (range_bad(yr)) flags[par] = 1;    // after the barrier that follows tid 0's reset; read after the next one
 
     // ---- Q | K | V columns of this wave for every row of the tile -> the wave's table
 #pragma unroll

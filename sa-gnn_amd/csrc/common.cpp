@@ -34,20 +34,23 @@ int hip_fail(hipError_t e, const char* what) {
   return (int)e;
 }
 
-bool force_valu() {
-  const char* v = getenv("SAGNN_FUSION");
-  return v && strcmp(v, "valu") == 0;
-}
+// The arithmetic engine of the GEMM-shaped fusion stages: chosen per CALLING THREAD through the C ABI
+// (sagnn_set_engine), never through the environment; the default is the f16 x 2 split.
+static thread_local int tl_engine = SAGNN_ENGINE_F16X2;
+bool force_valu() { return tl_engine == SAGNN_ENGINE_VALU; }
+bool force_f32_mfma() { return tl_engine == SAGNN_ENGINE_F32; }
 
-bool force_f32_mfma() {
-  const char* v = getenv("SAGNN_GEMM");
-  return v && strcmp(v, "f32") == 0;
-}
+}  // namespace sagnn
 
-bool force_bf16x3() {
-  const char* v = getenv("SAGNN_GEMM");
-  return v && strcmp(v, "bf16x3") == 0;
+extern "C" int sagnn_set_engine(int engine) {
+  if (engine != SAGNN_ENGINE_F16X2 && engine != SAGNN_ENGINE_F32 && engine != SAGNN_ENGINE_VALU)
+    return sagnn::fail(SAGNN_ERR_ARG, "sagnn_set_engine: unknown engine %d", engine);
+  sagnn::tl_engine = engine;
+  return SAGNN_OK;
 }
+extern "C" int sagnn_get_engine(void) { return sagnn::tl_engine; }
+
+namespace sagnn {
 
 int ensure_dynamic_lds(const void* kernel, size_t bytes) {
   static std::mutex mu;

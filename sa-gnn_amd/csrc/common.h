@@ -42,18 +42,12 @@ int lstm_fwd_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, 
                   const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h,
                   float* gates_out, float* c_out, const float* h_init, int64_t ld_hi, const float* c_init,
                   float* c_final, hipStream_t s);
-// lstm_split.hip: the same LSTM on the bf16 matrix cores with exactly split fp32 operands
-bool lstm_split_supported(int d);
-int lstm_fwd_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W,
-                   const float* b, float forget_bias, const float* drop, float* h, int64_t ld_h, float* gates_out,
-                   float* c_out, const float* h_init, int64_t ld_hi, const float* c_init, float* c_final,
-                   hipStream_t s);
 // lstm_f16.hip: the same LSTM on the f16 matrix cores, operands split in two round-to-nearest pieces (default engine)
 bool lstm_f16_supported(int d);
 int lstm_fwd_f16(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, const float* W, const float* b,
                  float forget_bias, const float* drop, float* h, int64_t ld_h, float* gates_out, float* c_out,
                  const float* h_init, int64_t ld_hi, const float* c_init, float* c_final, hipStream_t s);
-// attn_split.hip: layer norm + Q|K|V + attention + mean with the products on the bf16 matrix cores
+// attn_split.hip: layer norm + Q|K|V + attention + mean with the products on the f16 matrix cores (split operands)
 bool mhsa_split_supported(int d, int t, int heads);
 int ln_mhsa_mean_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
                        const float* gamma, const float* beta, float eps, int apply_ln, const float* Wq,
@@ -64,8 +58,7 @@ bool lstm_split128_supported(int d);
 int lstm_fwd_split128(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, const float* W, const float* b,
                       float forget_bias, float* h, int64_t ld_h, float* gates_out, float* c_out, const float* h_init,
                       int64_t ld_hi, const float* c_init, float* c_final, hipStream_t s);
-bool force_f32_mfma();  // SAGNN_GEMM=f32 in the environment: the exact-fp32 MFMA kernels (A/B reference)
-bool force_bf16x3();    // SAGNN_GEMM=bf16x3: the six-product bf16 form where the default is the three-product f16 one
+bool force_f32_mfma();  // the calling thread chose SAGNN_ENGINE_F32 (sagnn_set_engine): the exact-fp32 MFMA kernels
 bool mhsa_mfma_supported(int d, int t, int heads);
 int ln_mhsa_mean_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,
                       const float* gamma, const float* beta, float eps, int apply_ln, const float* Wq,
@@ -89,7 +82,7 @@ int dense_nn_any(const float* X, int64_t ldx, int64_t n, int din, int dout, cons
                  const float* bias, float* Y, int64_t ldy, int accumulate, hipStream_t s);
 int dense_tn_any(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW,
                  int64_t lddw, float* db, hipStream_t s);
-bool force_valu();  // SAGNN_FUSION=valu in the environment
+bool force_valu();  // the calling thread chose SAGNN_ENGINE_VALU
 
 // ---- optional per-launch timing (sagnn_profile_*) -------------------------------------------
 enum ProfileKind { kProfSpmmRows = 0, kProfSpmmFixup = 1, kProfLstm = 2, kProfLayerNorm = 3, kProfMhsa = 4 };

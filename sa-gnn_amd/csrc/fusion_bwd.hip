@@ -539,11 +539,11 @@ extern "C" int sagnn_adam_multi_f32(int n_tensors, float* const* params, const f
   if (!params || !grads || !m || !v || !counts || !l2) return sagnn::fail(SAGNN_ERR_NULL, "null table pointer");
   if (step < 1) return sagnn::fail(SAGNN_ERR_ARG, "step counts from 1");
   const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
-  for (int i0 = 0; i0 < n_tensors; i0 += kAdamMaxTensors) {
+  for (int i = 0; i < n_tensors;) {   // one launch per kAdamMaxTensors NON-EMPTY tensors; `i` carries over between launches
     AdamTable tb{};
     int64_t blocks = 0;
     int k = 0;
-    for (int i = i0; i < n_tensors && k < kAdamMaxTensors; ++i) {
+    for (; i < n_tensors && k < kAdamMaxTensors; ++i) {
       if (counts[i] < 0) return sagnn::fail(SAGNN_ERR_ARG, "tensor %d: count = %lld", i, (long long)counts[i]);
       if (counts[i] == 0) continue;
       if (!params[i] || !m[i] || !v[i]) return sagnn::fail(SAGNN_ERR_NULL, "tensor %d: null param / m / v", i);

@@ -967,12 +967,9 @@ int lstm_fwd_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, 
                   float* c_final, hipStream_t s) {
   const bool save = gates_out != nullptr;
   const bool split_ok = !force_f32_mfma() && !(save && drop) && ld_h < (1 << 22) && (int64_t)t * d < (1 << 18);
-  if (lstm_f16_supported(d) && split_ok && !force_bf16x3())
+  if (lstm_f16_supported(d) && split_ok)
     return lstm_fwd_f16(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, h_init, ld_hi, c_init,
                         c_final, s);
-  if (lstm_split_supported(d) && split_ok)
-    return lstm_fwd_split(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, h_init, ld_hi,
-                          c_init, c_final, s);
   // 32-row tiles are addressed with 32-bit byte offsets from a per-tile base
   if (ld_n >= (1 << 24) || ld_h >= (1 << 24) || (int64_t)t * d >= (1 << 20))
     return fail(SAGNN_ERR_ARG, "MFMA LSTM: row strides must stay below 2^24 floats");

@@ -9,13 +9,13 @@
 // gate math joins with one fma) instead of three bf16 pieces and six products — the same accuracy class
 // at 3/6 of the MFMAs and 2/3 of the LDS images and weight registers.
 //
-// f16 has 5 exponent bits: |v| > 65504 does not fit a piece. Small values are safe (the matrix core
-// honours f16 denormals, checked in the same microbenchmark; a denormal head only moves bits into the
-// scaled residual). LARGE ones are detected — every x / initial-h value passes through a running
-// max on its way into LDS, W when the fragments are built — and a workgroup that saw one re-evaluates
-// its 96-row tile after the fast pass with plain fp32 fmaf chains (the block after the step loop), so the results
-// are those of an fp32 evaluation for every finite input; the fast path carries two extra VALU
-// operations per 16 bytes of x for it.
+// f16 has 5 exponent bits, so the split holds inside a window (f16_split.h, RANGE): |v| < 32768, and no 4-element
+// segment that is non-zero but below 2^-18 as a whole. Every x / initial-h value passes through a RangeTrack on
+// its way into LDS (W when the fragments are built), and a workgroup that saw a value outside the window
+// re-evaluates its 96-row tile after the fast pass with plain fp32 fmaf chains (the block after the step loop),
+// from the tile's ORIGINAL initial state (c_final is written once, by whichever pass is the last): an input row of
+// 1e-30 or of 1e30 gets the results of an fp32 evaluation. The fast path carries five extra VALU operations per
+// 16 bytes of x for it.
 #include <type_traits>
 #include <utility>
 
@@ -58,7 +58,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // which they are issued and the MFMA gap each one goes to come from a list scheduler over their dependency
 // graph (tools/gen_lstm_schedule.py): at most one transcendental per gap, an even share of the issue cycles,
 // and nothing reads a result of its own gap.
-constexpr int kGateOps = 118, kXOps = 13;
+constexpr int kGateOps = 118, kXOps = 16;
 #include "lstm_f16_schedule.inc"
 template <int NM, bool XO>
 __host__ __device__ constexpr int sched_start(int i) {
@@ -79,9 +79,6 @@ __device__ __forceinline__ void lds_barrier() {
 
 __device__ __forceinline__ float sigmoid_e2(float z) {   // the fast path's own formulas
   return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * z));
-}
-__device__ __forceinline__ float tanh_e2(float z) {
-  return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.f * 1.44269504088896340736f * z)), 1.f);
 }
 
 template <int D, bool SAVE, bool DROP>
@@ -104,7 +101,7 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
   extern __shared__ __attribute__((aligned(16))) char lds[];
   char* const Xp = lds;                         // 2 x 2 images
   char* const Hp = lds + 4 * PLANE;             // 2 x 2 images
-  int* const flags = reinterpret_cast<int*>(lds + 8 * PLANE);   // [0], [1]: large input seen in the tile of that parity; [2]: in W
+  int* const flags = reinterpret_cast<int*>(lds + 8 * PLANE);   // [0], [1]: input outside the split's window seen in the tile of that parity; [2]: in W
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -121,17 +118,17 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
   // heads in wf[..][0], scaled residuals in wf[..][1]
   i32x4 wf[4][KS][2];
   {
-    float wmax = 0.f;
+    RangeTrack wr = range_init();
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         float wv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {  // column scale of the gate's non-linearity folded into W (see bc below)
+        for (int j = 0; j < 8; ++j)  // column scale of the gate's non-linearity folded into W (see bc below)
           wv[j] = W[(size_t)(32 * ks + 8 * q + j) * NC + g * D + 16 * wave + m] * (g == 1 ? 2.f * kL2E : -kL2E);
-          wmax = __builtin_fmaxf(wmax, __builtin_fabsf(wv[j]));
-        }
+        range_seg4(wr, wv[0], wv[1], wv[2], wv[3]);
+        range_seg4(wr, wv[4], wv[5], wv[6], wv[7]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int hd = head2(wv[2 * e], wv[2 * e + 1]);
@@ -139,7 +136,7 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
           wf[g][ks][1][e] = tail_hi(tail_lo(resid<0>(hd, wv[2 * e]), k4096), resid<1>(hd, wv[2 * e + 1]), k4096);
         }
       }
-    if (wmax > kF16Max) flags[2] = 1;     // ordered before its first reader by the tile loop's barriers
+    if (range_bad(wr)) flags[2] = 1;      // ordered before its first reader by the tile loop's barriers
   }
   // Gate non-linearities are evaluated as exp2(t), t = k (pre-activation + bias), k = -log2(e) for the
   // sigmoids and 2 log2(e) for tanh(j): k is folded into this wave's columns of W and k * bias is what the
@@ -168,7 +165,7 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
     const int64_t row0 = tile * kRows;
     const int rows_valid = (int)(n - row0 < kRows ? n - row0 : kRows);
     if (tid == 0) flags[par] = 0;   // two tiles (and their barriers) after its last reader
-    float xmax = 0.f;               // largest |x| / |h_init| this thread moved into LDS
+    RangeTrack xrng = range_init();  // range of the x / h_init values this thread moved into LDS
     float4 xr[NFILL];
     auto fetch_x = [&](int ts) {
 #pragma unroll
@@ -205,13 +202,13 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
         const int r = p * RPP + fr;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < rows_valid) v = *reinterpret_cast<const float4*>(h_init + (row0 + r) * ld_hi + fc4);
-        xmax = max3abs(max3abs(xmax, v.x, v.y), v.z, v.w);
+        range_seg4(xrng, v.x, v.y, v.z, v.w);
         write_pieces(Hp, r, fc4, v);
       }
     }
 #pragma unroll
     for (int p = 0; p < NFILL; ++p) {
-      xmax = max3abs(max3abs(xmax, xr[p].x, xr[p].y), xr[p].z, xr[p].w);
+      range_seg4(xrng, xr[p].x, xr[p].y, xr[p].z, xr[p].w);
       write_pieces(Xp, p * RPP + fr, fc4, xr[p]);
     }
     lds_barrier();
@@ -235,7 +232,8 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
 
       f32x4 ahi[4], alo[4];            // tile in flight
       int xw0[2][2], xw1[2][2], xoff[2];   // pieces of the two x passes being written
-      float xq[2][4];
+      float xq[2][4], xs[2];
+      uint32_t xsb[2];
       f32x4 ga[4], gl[4];              // pre-activations of the tile whose gate math is being interleaved
       f32x4 dv;                        // dropout scale of that tile
       float tt[4][4], pr[4], cn[4], u[4], hn[4], hv[4], r1[4];
@@ -353,11 +351,17 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
             xw1[PS][1] = tail_lo(xq[PS][2], k4096);
           } else if constexpr (X == 9) {
             xw1[PS][1] = tail_hi(xw1[PS][1], xq[PS][3], k4096);
-          } else if constexpr (X == 10) {
-            xmax = max3abs(xmax, xv[0], xv[1]);
+          } else if constexpr (X == 10) {       // the segment's max |v| and what it does to the tile's range (f16_split.h, RANGE)
+            xs[PS] = maxabs3(xv[0], xv[1], xv[2]);
           } else if constexpr (X == 11) {
-            xmax = max3abs(xmax, xv[2], xv[3]);
+            xs[PS] = maxabs_acc(xs[PS], xv[3]);
             xoff[PS] = xrow * (D * 2) + (((fc4_ >> 3) ^ swz<D>(xrow)) << 4) + ((fc4_ >> 2) & 1) * 8;
+          } else if constexpr (X == 12) {
+            xrng.hi = maxabs_acc(xrng.hi, xs[PS]);
+          } else if constexpr (X == 13) {
+            xsb[PS] = __builtin_bit_cast(uint32_t, xs[PS]) - 1u;
+          } else if constexpr (X == 14) {
+            xrng.lo = xsb[PS] < xrng.lo ? xsb[PS] : xrng.lo;
           } else {
             *reinterpret_cast<i32x2*>(Xnxt + xoff[PS]) = i32x2{xw0[PS][0], xw0[PS][1]};
             *reinterpret_cast<i32x2*>(Xnxt + PLANE + xoff[PS]) = i32x2{xw1[PS][0], xw1[PS][1]};
@@ -415,16 +419,19 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
       // x_{ts+1} went into the other buffer inside the step (its loads were issued at the top of it)
       if (ts + 1 < t) lds_barrier();   // x_{ts+1} and every wave's columns of h_{ts+1} are in place; x_ts / h_ts are free
     }
-    if (c_final) {
+    if (range_bad(xrng)) flags[par] = 1;
+    lds_barrier();            // flags settled; the images are free (the next tile's fills overwrite them)
+    const bool redo = (flags[par] | flags[2]) != 0;   // block-uniform
+    // c_final may BE c_init (a continued state updated in place): it is written once, by the pass that counts, so the
+    // redo below still finds the tile's initial cell state where the caller put it
+    if (c_final && !redo) {
 #pragma unroll
       for (int bt = 0; bt < kBT; ++bt)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, c[bt]), rs_cf, ((bt * 16 + m) * D + hid0) * 4, 0, 0);
     }
-    if (xmax > kF16Max) flags[par] = 1;
-    lds_barrier();            // flags settled; the images are free (the next tile's fills overwrite them)
-    if (flags[par] | flags[2]) {
+    if (redo) {
       __syncthreads();        // this tile's global stores have left: the slow pass rewrites the same addresses
-      // ---- a value beyond the f16 range went into this tile (or sits in W): the whole tile again as plain fp32
+      // ---- a value outside the split's window went into this tile (or sits in W): the whole tile again as plain fp32
       // fmaf chains, thread per (row, hidden unit), h and c of the tile in LDS. Never taken on sane data.
       float* const hs = reinterpret_cast<float*>(lds);     // [2][kRows][D]
       float* const cs = hs + 2 * kRows * D;                 // [kRows][D]
@@ -454,9 +461,11 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
 #pragma unroll
             for (int g = 0; g < 4; ++g) a[g] = fmaf(hv, W[(size_t)(D + k) * NC + g * D + uu], a[g]);
           }
-          const float gi = sigmoid_e2(a[0]), gj = tanh_e2(a[1]), gf = sigmoid_e2(a[2]), go = sigmoid_e2(a[3]);
+          // tanhf, not the fast path's 1 - 2 / (1 + 2^t): a tile comes here also because a row is tiny as a whole, and
+          // such a row's h is as small as its x — only a tanh that is relatively accurate near zero keeps it
+          const float gi = sigmoid_e2(a[0]), gj = tanhf(a[1]), gf = sigmoid_e2(a[2]), go = sigmoid_e2(a[3]);
           const float cnew = fmaf(cs[idx], gf, gi * gj);
-          const float hnew = tanh_e2(cnew) * go;
+          const float hnew = tanhf(cnew) * go;
           cs[idx] = cnew;
           hnx[idx] = hnew;
           const int64_t e_td = ((row0 + r) * t + ts) * D + uu;

@@ -14,7 +14,7 @@
 //     gate math runs beside the other's products;
 //   * x_t and h_{t-1} of a 64-row tile are split into pieces and shared through LDS as two f16 images
 //     [64][256] (16-byte slots XOR-swizzled with the row: 512-byte rows start on the same bank);
-//   * a tile that met a value beyond the f16 range (or W holding one) is evaluated again by the same lanes
+//   * a tile that met a value outside the window of the split (f16_split.h, RANGE; or W holding one) is evaluated again by the same lanes
 //     with fp32 fmaf chains (they still hold their c_{t-1}) and stored over the fast pass's results;
 //   * c_t is kept in the caller's h buffer one interval AHEAD (slot ts + 1 is free until step ts + 1
 //     writes h there; the same lane reads c and then writes h at those addresses), so the entry needs no
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
 
   // ---- W slice as A fragments: A row mm = lane & 15 -> hidden hb + 2 (mm >> 2) + ((mm & 3) >> 1), gate 2 tile + (mm & 1);
   //      the gate's exp2 scale is folded in (lstm_split.hip)
-  int* const flags = reinterpret_cast<int*>(lds + 2 * PLANE);   // [0], [1]: value beyond the f16 range in the tile of that parity; [2]: in W
+  int* const flags = reinterpret_cast<int*>(lds + 2 * PLANE);   // [0], [1]: value outside the split's window in the tile of that parity; [2]: in W
   float k4096 = 4096.f;
   asm volatile("" : "+v"(k4096));
   if (tid < 3) flags[tid] = 0;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
   i32x4 wf[2][KS][2];
   {
     const int a_hid = hb + 2 * (m >> 2) + ((m & 3) >> 1);
-    float wmax = 0.f;
+    RangeTrack wr = range_init();
 #pragma unroll
     for (int tile = 0; tile < 2; ++tile) {
       const int gate = 2 * tile + (m & 1);
@@ -73,10 +73,9 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
       for (int ks = 0; ks < KS; ++ks) {
         float wv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          wv[j] = W[(size_t)(32 * ks + 8 * q + j) * NC + gate * D + a_hid] * sc;
-          wmax = __builtin_fmaxf(wmax, __builtin_fabsf(wv[j]));
-        }
+        for (int j = 0; j < 8; ++j) wv[j] = W[(size_t)(32 * ks + 8 * q + j) * NC + gate * D + a_hid] * sc;
+        range_seg4(wr, wv[0], wv[1], wv[2], wv[3]);
+        range_seg4(wr, wv[4], wv[5], wv[6], wv[7]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int hd = head2(wv[2 * e], wv[2 * e + 1]);
@@ -85,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
         }
       }
     }
-    if (wmax > kF16Max) flags[2] = 1;   // ordered before its first reader by the tile loop's barriers
+    if (range_bad(wr)) flags[2] = 1;    // ordered before its first reader by the tile loop's barriers
   }
   f32x4 bc[2];   // k * (bias [+ forget bias]) per C row of the two tiles
 #pragma unroll
@@ -99,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
 
   // fill mapping: 32 threads per row (float4 each), 8 rows per pass
   const int fr = tid >> 5, fc4 = (tid & 31) * 4;
-  float xmax = 0.f;   // largest |value| this thread moved into the images of the current tile
+  RangeTrack xr = range_init();   // range of what this thread moved into the images of the current tile (f16_split.h, RANGE)
   auto fill_half = [&](const float* src, int64_t ld, int64_t row0, int rows_valid, int kbase) {
     float4 v[kRows / 8];
 #pragma unroll
@@ -111,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
 #pragma unroll
     for (int p = 0; p < kRows / 8; ++p) {
       const int r = p * 8 + fr;
-      xmax = max3abs(max3abs(xmax, v[p].x, v[p].y), v[p].z, v[p].w);
+      range_seg4(xr, v[p].x, v[p].y, v[p].z, v[p].w);
       const int p0 = head2(v[p].x, v[p].y), p1 = head2(v[p].z, v[p].w);
       const int col = kbase + fc4;
       const int off = r * (K2 * 2) + ((((col >> 3)) ^ (r & 31)) << 4) + ((col >> 2) & 1) * 8;
@@ -125,11 +124,11 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
     const int64_t row0 = tile * kRows;
     const int rows_valid = (int)(n - row0 < kRows ? n - row0 : kRows);
     if (tid == 0) flags[par] = 0;   // two tiles (and their barriers) after its last reader
-    xmax = 0.f;
+    xr = range_init();
     fill_half(x_t, ld_x, row0, rows_valid, 0);
     if (!FIRST) fill_half(h_prev, ld_hp, row0, rows_valid, D);
     lds_barrier();
-    if (xmax > kF16Max) flags[par] = 1;   // after the barrier that follows the reset; read after the next one
+    if (range_bad(xr)) flags[par] = 1;    // after the barrier that follows the reset; read after the next one
 
     int m_ = m, q_ = q;
     asm volatile("" : "+v"(m_), "+v"(q_));
@@ -187,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
     }
     lds_barrier();   // every wave has read the images before the next tile's fill
     if (flags[par] | flags[2]) {
-      // ---- a value beyond the f16 range: this lane's rows and units again as fp32 fmaf chains, stored over the fast pass
+      // ---- a value outside the split's window: this lane's rows and units again as fp32 fmaf chains, stored over the fast pass
       __syncthreads();   // the fast pass's stores have left
 #pragma unroll 1
       for (int bt = 0; bt < kBT; ++bt) {
@@ -212,11 +211,11 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
               for (int g = 0; g < 4; ++g) a[g] = fmaf(hv, W[(size_t)(D + k) * NC + g * D + hid + e], a[g]);
             }
           act[0][e] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * a[0]));
-          act[1][e] = fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.f * kL2E * a[1])), 1.f);
+          act[1][e] = tanhf(a[1]);   // relatively accurate near zero: a row that is tiny as a whole keeps its h (lstm_f16_kernel.h)
           act[2][e] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * a[2]));
           act[3][e] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-kL2E * a[3]));
           cn[e] = fmaf(cps[bt][e], act[2][e], act[0][e] * act[1][e]);
-          hn[e] = fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(cn[e] * (2.f * kL2E))), 1.f) * act[3][e];
+          hn[e] = tanhf(cn[e]) * act[3][e];
         }
         *reinterpret_cast<f32x2*>(h_out + grow * ld_h + hid) = hn;
         if (c_out) *reinterpret_cast<f32x2*>(c_out + grow * ld_c + hid) = cn;

@@ -287,7 +287,10 @@ class Recommender:
         p = the copies' highest score, j = its first copy — counted directly, O(candidates) per user instead of
         an argsort of [batch, testSize] (15 ms per batch: 80 % of a test epoch)."""
         shoot = args.shoot if shoot is None else shoot
-        preds = np.asarray(preds)
+        # a NaN score never outranks anything: under the reference's sort a NaN positive (the LAST candidate) stays
+        # last, i.e. a miss — left as NaN, p_best would compare False everywhere and count as rank 0 (a diverged
+        # model would report HR = 1)
+        preds = np.where(np.isnan(preds), -np.inf, preds)
         locs = np.stack([np.asarray(t) for t in tstLocs])                      # [B, C]
         B, C = locs.shape
         target = np.asarray([(-1 if t is None else t) for t in temTst[:B]])[:, None]

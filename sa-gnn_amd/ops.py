@@ -12,6 +12,34 @@ from ._lib import PlanInfo, Tuning, check
 
 SUPPORTED_D = tuple(range(4, 257, 4))
 
+# sagnn_set_engine (include/sagnn.h): arithmetic engine of the GEMM-shaped fusion stages, per calling thread
+ENGINES = {"f16x2": 0, "f32": 1, "valu": 2}
+
+
+def set_engine(name: str) -> None:
+    check(_lib.load().sagnn_set_engine(ENGINES[name]))
+
+
+def get_engine() -> str:
+    code = _lib.load().sagnn_get_engine()
+    return next(k for k, v in ENGINES.items() if v == code)
+
+
+class engine:
+    """`with ops.engine("f32"): ...` — runs the block under that engine and restores the caller's."""
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        self.prev = get_engine()
+        set_engine(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        set_engine(self.prev)
+        return False
+
 
 def _stream() -> int:
     # the raw handle of torch's current stream; torch.cuda.current_stream() builds a Stream object per call
@@ -250,8 +278,7 @@ def _vec(name: str, v: torch.Tensor, numel: int):
 
 def _wide(d: int) -> bool:
     """d handled by the 'wide' MFMA composition (multiples of 32 other than the fused 32 / 64)."""
-    import os
-    return d % 32 == 0 and d not in (32, 64) and os.environ.get("SAGNN_FUSION") != "valu"
+    return d % 32 == 0 and d not in (32, 64) and _lib.load().sagnn_get_engine() != ENGINES["valu"]
 
 
 def lstm_fwd(x: torch.Tensor, W: torch.Tensor, b: torch.Tensor, forget_bias: float = 1.0,

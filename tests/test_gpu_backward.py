@@ -146,7 +146,7 @@ def test_fused_bptt_matches_step_loop(dev, d, t, n, monkeypatch):
     scale = torch.from_numpy(((rng.random((n, t, d)) < 0.7) / 0.7).astype(np.float32)).to(dev)
     grads = {}
     for mode in ("fused", "steps"):
-        monkeypatch.setenv("SAGNN_BPTT", mode)
+        monkeypatch.setattr(ag, "FUSED_BPTT", mode == "fused")
         xd = x.clone().requires_grad_(True)
         pd = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in p.items()}
         ag.interval_fusion(xd, pd, 16, drop_scale=scale).backward(gout)
@@ -173,6 +173,25 @@ def test_adam_step_matches_tf_formula(dev):
         v = 0.999 * v + 0.001 * gg * gg
         p = p - lr * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step) * m / (np.sqrt(v) + 1e-8)
     np.testing.assert_allclose(params["w"].cpu().numpy(), p, rtol=1e-4, atol=1e-5)
+
+
+def test_adam_multi_more_tensors_than_one_table_with_an_empty_one(dev):
+    """sagnn_adam_multi_f32 walks its tensors in tables of 48 non-empty ones. 60 tensors with an empty one in the
+    first table: the second launch must start where the first stopped — every tensor takes exactly ONE step."""
+    from sa_gnn_amd import ops
+    rng = np.random.default_rng(5)
+    sizes = [int(s) for s in rng.integers(4, 3000, size=60)]
+    sizes[10] = 0
+    p0 = [rng.standard_normal(s).astype(np.float32) for s in sizes]
+    g0 = [rng.standard_normal(s).astype(np.float32) for s in sizes]
+    params = {f"w{i}": torch.from_numpy(a.copy()).to(dev) for i, a in enumerate(p0)}
+    opt = ops.Adam(params, lr=1e-2, reg=1e-2, reg_names={f"w{i}" for i in range(0, 60, 2)})
+    opt.step({f"w{i}": torch.from_numpy(g).to(dev) for i, g in enumerate(g0)})
+    for i in range(60):
+        gg = g0[i].astype(np.float64) + (2 * 1e-2 * p0[i] if i % 2 == 0 else 0.0)
+        m, v = 0.1 * gg, 0.001 * gg * gg
+        want = p0[i] - 1e-2 * np.sqrt(1 - 0.999) / (1 - 0.9) * m / (np.sqrt(v) + 1e-8)
+        np.testing.assert_allclose(params[f"w{i}"].cpu().numpy(), want, rtol=1e-4, atol=1e-5, err_msg=f"tensor {i}")
 
 
 def test_gnn_interval_backward_with_duplicated_stored_entries(dev):

@@ -44,15 +44,11 @@ def test_dense_tn(dev, n, din, dout):
 
 @pytest.mark.parametrize("engine", ["f16x2", "f32"])
 @pytest.mark.parametrize("rows,d", [(1000, 64), (31, 64), (40007, 64), (513, 32), (70001, 32)])
-def test_attn_bwd_tail(dev, rows, d, engine, monkeypatch):
+def test_attn_bwd_tail(dev, rows, d, engine):
     """sagnn_attn_bwd_tail_f32: dy (over y), dW and db of the three dense layers in one pass over
     dQ|dK|dV, against float64 matmuls; sizes from one ragged chunk to many chunks per block. Both engines:
-    the f16 matrix cores (default) and the f32-MFMA kernel of round 1 (SAGNN_GEMM=f32)."""
+    the f16 matrix cores (default) and the f32-MFMA kernel of round 1 (sagnn_set_engine(SAGNN_ENGINE_F32))."""
     from sa_gnn_amd import _lib, ops
-    if engine == "f32":
-        monkeypatch.setenv("SAGNN_GEMM", "f32")
-    else:
-        monkeypatch.delenv("SAGNN_GEMM", raising=False)
     lib = _lib.load()
     gen = torch.Generator(device="cpu").manual_seed(rows + d)
     y = torch.randn((rows, d), generator=gen)
@@ -62,8 +58,9 @@ def test_attn_bwd_tail(dev, rows, d, engine, monkeypatch):
     dW = torch.zeros((d, 3 * d), device=dev)
     db = torch.zeros(3 * d, device=dev)
     assert lib.sagnn_attn_bwd_tail_supported(d)
-    ops.check(lib.sagnn_attn_bwd_tail_f32(yd.data_ptr(), gd.data_ptr(), rows, d, Wd.data_ptr(), dW.data_ptr(),
-                                          db.data_ptr(), None))
+    with ops.engine(engine):
+        ops.check(lib.sagnn_attn_bwd_tail_f32(yd.data_ptr(), gd.data_ptr(), rows, d, Wd.data_ptr(), dW.data_ptr(),
+                                              db.data_ptr(), None))
     want_dy = dqkv.double() @ W.double().T
     want_dW = y.double().T @ dqkv.double()
     torch.testing.assert_close(yd.cpu().double(), want_dy, rtol=1e-4, atol=1e-5)
@@ -74,9 +71,11 @@ def test_attn_bwd_tail(dev, rows, d, engine, monkeypatch):
 
 @pytest.mark.parametrize("rows,d", [(1000, 64), (20011, 64), (777, 32)])
 def test_attn_bwd_tail_beyond_the_f16_range(dev, rows, d):
-    """The tail's products run on two-piece f16 operands. A chunk of 32 rows that holds a value beyond 65504 (here a
-    gradient of 1e6, a y of -3e5 and an isolated 2e30) takes no part in the matrix-core products: the block evaluates
-    it with fp32 fmaf chains. dy, dW and db of the flagged chunks, of their neighbours and of the rest must match."""
+    """The tail's products run on two-piece f16 operands. Gradient rows are scaled into the split's window by exact
+    powers of two (a gradient of 1e6 or an isolated 2e30 is an ordinary row after that); a chunk of 32 rows that
+    holds a y beyond the window (-3e5 here), or whose rows dwarf everything the block has met, takes no part in the
+    matrix-core products: the block evaluates it with fp32 fmaf chains. dy, dW and db of those chunks, of their
+    neighbours and of the rest must match."""
     from sa_gnn_amd import _lib, ops
     lib = _lib.load()
     gen = torch.Generator(device="cpu").manual_seed(3 * rows + d)

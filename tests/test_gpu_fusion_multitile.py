@@ -129,38 +129,34 @@ def test_attn_bwd_front_many_tiles_per_block(dev, d, t, n):
 
 
 @pytest.mark.parametrize("d,t,n", [(64, 3, 20_011), (32, 16, 9_001), (128, 6, 10_007)])
-def test_split_engines_match_f32_mfma_engine(dev, d, t, n, monkeypatch):
+def test_split_engine_matches_f32_mfma_engine(dev, d, t, n):
     """The fusion GEMMs run on the 16-bit matrix cores over SPLIT fp32 operands: two round-to-nearest f16 pieces and
-    three piece products, or (the d = 32 / 64 LSTM under SAGNN_GEMM=bf16x3) three exact bf16 pieces and six
-    products. Either is fp32-grade arithmetic, not a
-    half-precision GEMM: against the round-1 engine (v_mfma_f32_32x32x2_f32, an fmaf chain; SAGNN_GEMM=f32; at d = 128
-    the VALU LSTM + f32-MFMA dense products) the outputs differ by a few 1e-7 on h and 1e-6 on the fused rows, and all
-    are equally far from the float64 result."""
+    three piece products. That is fp32-grade arithmetic, not a half-precision GEMM: against the exact-fp32 engine
+    (v_mfma_f32_32x32x2_f32, an fmaf chain; sagnn_set_engine(SAGNN_ENGINE_F32); at d = 128 the VALU LSTM + f32-MFMA
+    dense products) the outputs differ by a few 1e-7 on h and 1e-6 on the fused rows, and both are equally far from
+    the float64 result."""
     from sa_gnn_amd import ops
     rng = np.random.default_rng(d + t)
     x = rng.standard_normal((n, t, d)).astype(np.float32)
     p, pd = _params(d, rng, dev)
     xd = torch.from_numpy(x).to(dev)
     outs = {}
-    for mode in ("f16x2", "bf16x3", "f32"):
-        if mode == "f16x2":
-            monkeypatch.delenv("SAGNN_GEMM", raising=False)
-        else:
-            monkeypatch.setenv("SAGNN_GEMM", mode)
-        h = ops.lstm_fwd(xd, pd["lstm_W"], pd["lstm_b"], 1.0)
-        f = ops.ln_mhsa_mean(h, pd["ln_gamma"], pd["ln_beta"], pd["Wq"], pd["bq"], pd["Wk"], pd["bk"], pd["Wv"], pd["bv"], 16)
+    for mode in ("f16x2", "f32"):
+        with ops.engine(mode):
+            h = ops.lstm_fwd(xd, pd["lstm_W"], pd["lstm_b"], 1.0)
+            f = ops.ln_mhsa_mean(h, pd["ln_gamma"], pd["ln_beta"], pd["Wq"], pd["bq"], pd["Wk"], pd["bk"], pd["Wv"], pd["bv"], 16)
         outs[mode] = (h.cpu().numpy().astype(np.float64), f.cpu().numpy().astype(np.float64))
+    assert ops.get_engine() == "f16x2"
     x64 = x.astype(np.float64)
     p64 = {k: v.astype(np.float64) for k, v in p.items()}
     h64 = O.basic_lstm(x64, p64["lstm_W"], p64["lstm_b"], 1.0)
     f64 = O.mhsa(O.layer_norm_td(h64, p64["ln_gamma"], p64["ln_beta"]), p64["Wq"], p64["bq"], p64["Wk"], p64["bk"], p64["Wv"],
                  p64["bv"], 16).mean(axis=1)
     e_f32 = max(np.abs(outs["f32"][0] - h64).max(), np.abs(outs["f32"][1] - f64).max())
-    for mode in ("f16x2", "bf16x3"):
-        assert np.abs(outs[mode][0] - outs["f32"][0]).max() <= 5e-6, mode
-        assert np.abs(outs[mode][1] - outs["f32"][1]).max() <= 2e-5, mode
-        e_split = max(np.abs(outs[mode][0] - h64).max(), np.abs(outs[mode][1] - f64).max())
-        assert e_split <= 2e-5 and e_split <= 3 * e_f32 + 1e-6, (mode, e_split, e_f32)
+    assert np.abs(outs["f16x2"][0] - outs["f32"][0]).max() <= 5e-6
+    assert np.abs(outs["f16x2"][1] - outs["f32"][1]).max() <= 2e-5
+    e_split = max(np.abs(outs["f16x2"][0] - h64).max(), np.abs(outs["f16x2"][1] - f64).max())
+    assert e_split <= 2e-5 and e_split <= 3 * e_f32 + 1e-6, (e_split, e_f32)
 
 
 @pytest.mark.parametrize("d,t,n", [(64, 3, 1_000), (32, 4, 777), (64, 2, 40_003), (128, 3, 700)])

@@ -28,7 +28,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in sagnn.h but not exported by libsagnn.so"
     assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES table out of sync with sagnn.h"
-    assert lib.sagnn_version() == 10200
+    assert lib.sagnn_version() == 10300
 
 
 def test_csr_check_errors():
@@ -250,3 +250,50 @@ def test_calc_res_counts_match_the_reference_loop_on_ties_and_duplicates():
             for c in range(C):
                 preds[b, c] = preds[b, np.argmax(locs[b] == locs[b][c])]
         np.testing.assert_allclose(Recommender.calcRes(preds, tem, locs, shoot=10), O.calc_res(preds, tem, locs, shoot=10))
+
+
+def test_calc_res_counts_a_nan_score_as_a_miss():
+    """A diverged model scores NaN. The reference's sort leaves a NaN positive where it is — last — so it misses;
+    the sort-free count must not turn `NaN > x == False` into rank 0 (HR = 1). +-inf keep their meaning."""
+    from oracle import selfgnn_oracle as O
+    from sa_gnn_amd.model import Recommender
+    rng = np.random.default_rng(1)
+    B, C = 5, 100
+    locs = [list(rng.permutation(1000)[:C]) for _ in range(B)]
+    tem = [l[-1] for l in locs]
+    preds = rng.standard_normal((B, C))
+    preds[0, :] = np.nan             # everything NaN
+    preds[1, -1] = np.nan            # only the positive
+    preds[2, :50] = np.nan           # half of the negatives: the positive competes with the finite half only
+    preds[2, -1] = 10.0
+    preds[3, -1] = np.inf
+    preds[4, -1] = -np.inf
+    got = [Recommender.calcRes(preds[j:j + 1], tem[j:j + 1], locs[j:j + 1], shoot=10) for j in range(B)]
+    assert got[0] == (0.0,) * 6 and got[1] == (0.0,) * 6 and got[4] == (0.0,) * 6
+    assert got[3] == (1.0,) * 6
+    for j in (0, 1, 3, 4):           # where Python's sort is well defined with a NaN in the list
+        assert got[j] == O.calc_res(preds[j:j + 1], tem[j:j + 1], locs[j:j + 1], shoot=10)
+    assert got[2][0] == 1.0
+
+
+def test_engine_is_chosen_per_thread_through_the_abi():
+    """sagnn_set_engine / sagnn_get_engine: no environment switch, no process-wide state."""
+    import threading
+    lib = _lib.load()
+    assert lib.sagnn_get_engine() == 0
+    assert lib.sagnn_set_engine(1) == 0 and lib.sagnn_get_engine() == 1
+    seen = []
+    th = threading.Thread(target=lambda: seen.append(lib.sagnn_get_engine()))
+    th.start(); th.join()
+    assert seen == [0]                                   # another thread still runs the default
+    assert lib.sagnn_set_engine(7) < 0 and lib.sagnn_get_engine() == 1
+    assert lib.sagnn_set_engine(0) == 0
+
+
+def test_adam_multi_batches_skip_empty_tensors_without_stepping_any_twice():
+    """More than 48 tensors (one launch's table) with an empty one among them: host-side argument walk only — the
+    launch itself needs a GPU (tests/test_gpu_train.py); here the walk must terminate and reject nothing."""
+    import ctypes
+    lib = _lib.load()
+    assert lib.sagnn_adam_multi_f32(0, None, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 1, None) == 0
+

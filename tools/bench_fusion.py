@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Times the interval-fusion kernels alone (LSTM, LN + MHSA + mean) at the roofline configuration's
 row count, for the three GEMM engines: the default (f16 matrix cores, operands split in two round-to-nearest
-pieces, three piece products), SAGNN_GEMM=bf16x3 (bf16 matrix cores, three exact pieces, six products) and
-SAGNN_GEMM=f32 (v_mfma_f32_32x32x2_f32), and prints how far the results are apart and how far each is from
+pieces, three piece products), and the exact-fp32 engine (v_mfma_f32_32x32x2_f32; ops.set_engine('f32')), and prints how far the results are apart and how far each is from
 the numpy oracle on a row slice.  python tools/bench_fusion.py [--n 15000000] [--t 2] [--d 64]"""
 import argparse
 import os
@@ -43,10 +42,7 @@ def main():
     res = {}
     engines = a.engines.split(",")
     for mode in engines:
-        if mode == "f16x2":
-            os.environ.pop("SAGNN_GEMM", None)
-        else:
-            os.environ["SAGNN_GEMM"] = mode
+        ops.set_engine(mode)
 
         def timed(fn):
             fn()

@@ -21,7 +21,7 @@ Operation numbers for U hidden units per lane (U = 4 is the list in lstm_f16_ker
   heads of h (U/2) | residuals (U) | tails (U) | LDS write | h store + c | stores of the training forward"""
 import sys
 
-K_X = 13
+K_X = 16
 
 
 class Ops:
@@ -77,7 +77,11 @@ def build(u, xpasses):
         deps[b + 7] |= {b + 6, b + 3}
         deps[b + 8].add(b + 4)
         deps[b + 9] |= {b + 8, b + 5}
-        deps[b + 12] |= {b + 0, b + 1, b + 7, b + 9, b + 11}
+        deps[b + 11].add(b + 10)                          # the segment's max |v| ...
+        deps[b + 12].add(b + 11)                          # ... into the running max,
+        deps[b + 13].add(b + 11)                          # ... its bits - 1
+        deps[b + 14].add(b + 13)                          # ... into the running min
+        deps[b + 15] |= {b + 0, b + 1, b + 7, b + 9, b + 11}
     cost = {k: (8 if k in o.trans else 4) for k in range(n)}
     cost[o.save] = 20
     return n, deps, cost, o.trans

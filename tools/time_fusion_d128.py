@@ -15,8 +15,7 @@ for n in (33_000, 1_000_000):
     want_h = O.basic_lstm(np.ascontiguousarray(x[:S].cpu().numpy()), pn["lstm_W"], pn["lstm_b"], 1.0)
     want_f = O.interval_fusion(np.ascontiguousarray(x[:S].cpu().numpy()), pn, 16)
     for mode in ("split", "valu"):
-        if mode == "valu": os.environ["SAGNN_FUSION"] = "valu"
-        else: os.environ.pop("SAGNN_FUSION", None)
+        ops.set_engine("valu" if mode == "valu" else "f16x2")
         def timed(fn, reps=5):
             fn(); torch.cuda.synchronize(); ts = []
             for _ in range(reps):
