@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — SelfGNN interval-propagation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks, see launch_command)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = one forward pass of the whole hot path over the synthetic power-law workload of
@@ -82,6 +82,9 @@ def parse():
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo = rehearsal of the N>1 pipeline on ONE GPU (every rank uses cuda:0, collectives "
                         "staged through host memory); never a performance run")
+    p.add_argument("--engine", default="f16x2", choices=["f16x2", "f32", "valu"],
+                   help="arithmetic engine of the fusion GEMMs for the timed steps (sagnn_set_engine); the default line also "
+                        "carries a short same-run block on the exact-fp32 engine (fusion_f32_engine)")
     p.add_argument("--graph", action="store_true",
                    help="N=1: time a hipGraph replay of the step (launch-bound small workloads); the "
                         "per-kernel event timing then comes from an extra eager pass before it")
@@ -95,13 +98,37 @@ def position_checksum(f: torch.Tensor) -> float:
     return float((f.abs().sum(dim=1, dtype=torch.float64) * w).sum() / (n * (n + 1) / 2.0))
 
 
+def launch_command(n_ranks: int, argv: list, port: int) -> list:
+    """The command `python bench.py --gpus N <argv>` runs as a child when it was started bare (no WORLD_SIZE in
+    the environment): one rank per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_ranks: int, argv: list) -> int:
+    """Starts the N ranks as a CHILD process (this process has not touched the GPU and never will), relays their
+    output — rank 0's one JSON line on stdout — and returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = launch_command(n_ranks, argv, port)
+    log("no WORLD_SIZE in the environment: starting", " ".join(cmd))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     import torch.distributed as dist
     from sa_gnn_amd import _lib, ops, synthetic
     from sa_gnn_amd.parallel import (ChunkedGather, RoundFusion, RowShardExchange, SplitIntervalRunner,
@@ -119,6 +146,7 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     lib = _lib.load()
+    ops.set_engine(a.engine)
 
     w = dict(WORKLOADS[a.workload])
     synthetic_wl = "t_per_gpu" in w
@@ -317,6 +345,7 @@ def main():
     launches_per_step = max(t_loc, 1) * 2 * L * 2 + 16 if a.stages != "train" else t_loc * 2 * L * 4 + 16
     lib.sagnn_profile_enable(a.steps * launches_per_step + 16)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    ops.range_redo_count(reset=True)
     sync()
     t1 = time.perf_counter()
     marks[0].record()
@@ -348,6 +377,7 @@ def main():
         sync()
         elapsed = time.perf_counter() - t1
         step_ms = [marks[s_].elapsed_time(marks[s_ + 1]) for s_ in range(a.steps)]
+    redo_tiles = ops.range_redo_count()       # tiles the f16 x 2 kernels re-evaluated in fp32 during the timed steps (0 = fast path throughout)
     elapsed = allmax(elapsed)
     if world > 1:
         te = torch.tensor([local_launch_edges], device=comm_dev, dtype=torch.int64)
@@ -383,6 +413,16 @@ def main():
                 "edges_per_sec": sum(r[2] for r in rs) / (t_ms * 1e-3) if t_ms > 0 else 0.0}
 
     allk = price(rows_k) or {"launches": 0, "avg_launch_ms": 0.0, "algorithmic_bytes_per_launch": 0.0, "achieved": 0.0, "frac": 0.0}
+    # one SpMM call = the row / chunk kernel + (when the graph has long rows) its fix-up launch: the roofline
+    # figure prices the CALL; the kernel-only average (what `rocprofv3 --kernel-trace --stats` lists per kernel) is kept beside it
+    fix_k = [r for r in rec if r[0] == 1]
+    call_ms = (sum(r[1] for r in rows_k) + sum(r[1] for r in fix_k)) / max(len(rows_k), 1)
+    kernel_only = {"spmm_rows_kernel_avg_ms": allk["avg_launch_ms"], "spmm_rows_kernel_frac": allk["frac"],
+                   "spmm_fixup_kernel_avg_ms": (sum(r[1] for r in fix_k) / len(fix_k)) if fix_k else 0.0,
+                   "spmm_fixup_launches": len(fix_k)}
+    if rows_k and call_ms > 0:
+        allk = dict(allk, avg_launch_ms=call_ms, achieved=allk["algorithmic_bytes_per_launch"] / (call_ms * 1e-3) / 1e9)
+        allk["frac"] = allk["achieved"] / HBM_PEAK_GBPS
     n_user_rows = plans[0][0].n_rows if plans else U
     side = {"user_side": price([r for r in rows_k if r[3] == n_user_rows]),        # rows = users, gathers item rows
             "item_side": price([r for r in rows_k if r[3] != n_user_rows])}        # rows = items, gathers user rows
@@ -421,9 +461,10 @@ def main():
                    "embed_dim": d, "gnn_layers": L, "heads": heads, "stages": a.stages,
                    "exchange": a.exchange if world > 1 else "none", "scale": a.scale, "item_zipf_s": a.zipf,
                    "launch": "hipGraph replay" if graph_mode else "eager",
-                   "fusion_gemm": {"": "f16x2 (two round-to-nearest f16 pieces, three piece products, fp32 accumulation)",
-                                   "bf16x3": "bf16x3 (LSTM: three exact bf16 pieces, six piece products)",
-                                   "f32": "f32 MFMA"}.get(os.environ.get("SAGNN_GEMM", ""), os.environ.get("SAGNN_GEMM", "")),
+                   "fusion_gemm": {"f16x2": "f16x2 (two round-to-nearest f16 pieces, three piece products, fp32 accumulation; "
+                                            "the SpMM itself is plain fp32)",
+                                   "f32": "f32 MFMA (v_mfma_f32_32x32x2_f32: an fp32 fmaf chain)",
+                                   "valu": "VALU fp32"}[ops.get_engine()],
                    "partitioning": (f"T < world: {sh.group_size} ranks per interval, target rows split inside a group; fusion row-sharded"
                                     if split else f"interval k -> rank k mod {world}; fusion row-sharded")},
         "ms_per_step_rank0": {"median": float(np.median(step_ms)), "min": float(np.min(step_ms)), "max": float(np.max(step_ms)),
@@ -431,14 +472,33 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "spmm_rows_kernel", "achieved": allk["achieved"], "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": allk["frac"], "traffic": traffic, "traffic_source": traffic_source,
                      "launches": allk["launches"], "avg_launch_ms": allk["avg_launch_ms"],
+                     "avg_launch_note": "per SpMM call: row / chunk kernel + its long-row fix-up launch (kernel_only lists them apart)",
+                     "kernel_only": kernel_only,
                      "algorithmic_bytes_per_launch": allk["algorithmic_bytes_per_launch"],
                      "frac_note": "algorithmic bytes / 8 TB/s HBM peak; hot rows served by the 256 MiB Infinity Cache are "
                                   "included, so this is beyond-L2 bandwidth, not pure HBM (a streaming copy reaches 6.3 TB/s)",
                      "by_direction": side},
+        "range_redo_tiles_rank0": redo_tiles,
         "stage_ms_per_step_rank0": stage_ms, "final_abs_mean": final_abs_mean, "final_position_checksum": final_pos,
         "spmm_only_edges_per_sec_rank0": (local_launch_edges * L) / ((stage_ms["spmm_rows"] + stage_ms["spmm_fixup"]) * 1e-3)
         if stage_ms["spmm_rows"] > 0 else None,
     }
+
+    # ---- the same steps on the exact-fp32 engine, same run (N = 1): what the f16 x 2 split buys ---------
+    if world == 1 and a.stages == "full" and a.engine == "f16x2" and not graph_mode:
+        with ops.engine("f32"):
+            step()
+            sync()
+            tb = time.perf_counter()
+            for _ in range(3):
+                step()
+            sync()
+            ms32 = (time.perf_counter() - tb) / 3 * 1e3
+        result["fusion_f32_engine"] = {"ms_per_step": ms32, "edges_per_sec": edges_per_step / (ms32 * 1e-3), "steps": 3,
+                                       "what": "the same step with sagnn_set_engine(SAGNN_ENGINE_F32): LSTM and attention products on "
+                                               "v_mfma_f32_32x32x2_f32 (an fp32 fmaf chain); SpMM unchanged"}
+        step()                                                # leave the f16x2 results in place for the checks below
+        sync()
 
     # ---- N > 1: where the step time goes (extra passes, outside the timed region) ---------------
     if world > 1 and a.stages == "full" and not a.no_breakdown:
@@ -565,19 +625,24 @@ def main():
                                          "what": "full-size item-side launch (rows = items, hub rows cut into chunks + fix-up) "
                                                  "vs oracle/c/tf1_path.c on the 16 heaviest rows + the first 200k rows"}
             del got, want, idx2, cols, sabs
-        # ---- fused embeddings of a >= 100k-row slice against the numpy oracle (model.py:135-155)
+        # ---- fused embeddings of >= 100k-row slices of BOTH node types against the numpy oracle (model.py:135-155)
         if a.stages == "full" and "final" in state:
-            Sf = min(131_072, U)
-            x = out_u[:, :Sf, :].permute(1, 0, 2).cpu().numpy()              # [Sf, T, d]
-            pnp = {k: v.detach().cpu().numpy() for k, v in prm[0].items()}
-            want = O.interval_fusion(np.ascontiguousarray(x), pnp, heads)
-            got = state["final"][0][:Sf].cpu().numpy()
-            e_abs = np.abs(got - want)
-            result["fused_max_abs_err"] = float(e_abs.max())
-            result["fused_check"] = {"rows": int(Sf), "intervals": int(T), "max_abs_ref": float(np.abs(want).max()),
-                                     "worst_over_tolerance": float((e_abs / (2e-5 + 1e-4 * np.abs(want))).max()),
-                                     "what": "users' fused embeddings rows 0..Sf-1 of the timed run (LSTM -> LN -> MHSA -> mean) "
-                                             "vs oracle/selfgnn_oracle.py interval_fusion on the same propagated rows"}
+            worst, checks = 0.0, {}
+            for tag, xs, n_rows, p, fin in (("users", out_u, U, prm[0], state["final"][0]), ("items", out_i, I, prm[1], state["final"][1])):
+                Sf = min(131_072 if tag == "users" else 65_536, n_rows)
+                x = xs[:, :Sf, :].permute(1, 0, 2).cpu().numpy()               # [Sf, T, d]
+                pnp = {k: v.detach().cpu().numpy() for k, v in p.items()}
+                want = O.interval_fusion(np.ascontiguousarray(x), pnp, heads)
+                got = fin[:Sf].cpu().numpy()
+                e_abs = np.abs(got - want)
+                worst = max(worst, float(e_abs.max()))
+                checks[tag] = {"rows": int(Sf), "max_abs_err": float(e_abs.max()), "max_abs_ref": float(np.abs(want).max()),
+                               "worst_over_tolerance": float((e_abs / (2e-5 + 1e-4 * np.abs(want))).max())}
+            result["fused_max_abs_err"] = worst
+            result["fused_check"] = {"intervals": int(T), "by_node_type": checks,
+                                     "worst_over_tolerance": max(c["worst_over_tolerance"] for c in checks.values()),
+                                     "what": "fused embeddings rows 0..S-1 of users and of items of the timed run (LSTM -> LN -> MHSA -> "
+                                             "mean) vs oracle/selfgnn_oracle.py interval_fusion on the same propagated rows"}
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

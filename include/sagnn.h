@@ -59,6 +59,10 @@ int sagnn_version(void);
 enum { SAGNN_ENGINE_F16X2 = 0, SAGNN_ENGINE_F32 = 1, SAGNN_ENGINE_VALU = 2 };
 int sagnn_set_engine(int engine);
 int sagnn_get_engine(void);
+/* Number of tiles / chunks the default engine has re-evaluated in fp32 on the current device since the last reset,
+ * because an operand left the window of the split (ARITHMETIC below): 0 on ordinary data. Synchronises the device
+ * (a diagnostic: tests use it to pin which path produced a result). */
+int sagnn_range_redo_count(int64_t* count, int reset);
 
 /* Copies the calling thread's last error text (NUL-terminated, truncated to cap) and
  * returns its full length. */

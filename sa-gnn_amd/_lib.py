@@ -42,6 +42,7 @@ SIGNATURES = {
     "sagnn_version": (c_int, []),
     "sagnn_set_engine": (c_int, [c_int]),
     "sagnn_get_engine": (c_int, []),
+    "sagnn_range_redo_count": (c_int, [POINTER(c_int64), c_int]),
     "sagnn_last_error": (c_size_t, [c_char_p, c_size_t]),
     "sagnn_profile_enable": (c_int, [c_int]),
     "sagnn_profile_read": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, POINTER(c_int)]),

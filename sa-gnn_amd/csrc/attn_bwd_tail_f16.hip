@@ -107,7 +107,7 @@ template <int D>
 __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd_tail_f16_kernel(float* __restrict__ y, const float* __restrict__ dqkv,
                                                                       int64_t rows, const float* __restrict__ W,
                                                                       float* __restrict__ dW, float* __restrict__ db,
-                                                                      int64_t n_chunks) {
+                                                                      int64_t n_chunks, unsigned int* __restrict__ redo_ctr) {
   constexpr int Q3 = 3 * D;              // dQKV columns
   constexpr int SUB = kRows * D * 2;     // bytes of one [32][D] f16 sub-image
   constexpr int PIECE = 4 * SUB;         // y | dQ | dK | dV
@@ -329,6 +329,7 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
       }
     } else {
       // ---- this chunk (or W) is outside the window: fp32 fmaf chains. dW first (it reads y), then dy.
+      if (tid == 0 && redo_ctr) atomicAdd(redo_ctr, 1u);
       for (int idx = tid; idx < D * Q3; idx += kBlock) {
         const int i = idx / Q3, o = idx - i * Q3;
         float acc = 0.f;
@@ -396,7 +397,7 @@ int launch(float* y, const float* dqkv, int64_t rows, const float* W, float* dW,
   const int64_t want = (D == 64 ? 1 : 2) * (int64_t)sagnn::cu_count_current();
   const int64_t blocks = n_chunks < want ? n_chunks : want;
   hipLaunchKernelGGL(attn_bwd_tail_f16_kernel<D>, dim3((unsigned)blocks), dim3(D == 64 ? 512 : 256), lds, s, y, dqkv, rows, W, dW,
-                     db, n_chunks);
+                     db, n_chunks, sagnn::redo_counter());
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }

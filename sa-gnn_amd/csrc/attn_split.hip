@@ -20,7 +20,7 @@
 //     split its queries; the pair's T q/k/v vectors are T contiguous 48-byte records. The mean over the
 //     queries is taken BEFORE the values are touched: out = sum_s w_s v_s with w_s = sum_t e_ts / (sum_s' e_ts' + 1e-8)
 //     / T — one multiply-add per (query, key) pair instead of d_k. Keys and values are taken in chunks of
-//     <= 8, the partial results of the LP lanes meet through the table, and the d_k outputs leave as one
+//     <= 8, the partial results of the LP lanes meet through DPP quad butterflies, and the d_k outputs leave as one
 //     vector store.
 //   A y or W value outside the window of the split (f16_split.h, RANGE: |v| >= 32768, or a 4-element segment that is
 //     non-zero but below 2^-18 as a whole — the normalised rows of an input of 1e-12) makes the workgroup redo that
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
     const float* __restrict__ beta, float eps, int apply_ln, const float* __restrict__ Wq,
     const float* __restrict__ bq, const float* __restrict__ Wk, const float* __restrict__ bk,
     const float* __restrict__ Wv, const float* __restrict__ bv, float* out, int64_t ld_out,
-    int64_t n_tiles, float* __restrict__ dqkv_out, float* __restrict__ y_out) {
+    int64_t n_tiles, float* __restrict__ dqkv_out, float* __restrict__ y_out, unsigned int* __restrict__ redo_ctr) {
   static_assert(!BWD || (LP == 1 && D <= 64), "the backward front keeps a pair in one lane");
   constexpr int NW = D >= 64 ? 4 : D / 16, NT = 64 * NW, KS = D / 32;
   constexpr int DK = D / 16;                    // 16 heads
@@ -276,6 +276,7 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
     }
     lds_barrier();   // table complete (wave-private), and every wave is done reading the y images
     if (flags[par] | flags[2]) {
+      if (tid == 0 && redo_ctr) atomicAdd(redo_ctr, 1u);
       // ---- slow_records: a y or W value does not fit an f16 piece. The tile's Q|K|V records again as fp32 fmaf
       // chains over y recomputed from x (the moments are still in LDS); thread per (row, matrix, column).
       constexpr int NCOL = 16 * NW;
@@ -422,20 +423,19 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
         for (int s = 0; s < KC; ++s) o += w[ch * KC + s] * v[s];
       }
       if (LP > 1) {
-        // The LP partial sums meet through the wave's own table: lane `part` > 0 parks its o in the q slot
-        // of the pair's record `part` (read into its owner's qv long ago: LDS operations of a wave
-        // complete in issue order), lane 0 adds them in a fixed order. Cross-lane forms measured WRONG
-        // here on ROCm 7.2 / gfx950: an update_dpp loop was miscompiled (two DPP instructions for four
-        // components) and __shfl_xor (ds_bpermute) returned stale values in ~1e-4 of the pairs with
-        // several workgroups per CU.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (part > 0) HeadVec<DK>::store(base + part * kRec, GS, o);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // The LP partial sums of a pair sit in LP neighbouring lanes of a quad: two DPP butterflies (quad_perm) and
+        // every lane of the pair holds the total. Each component goes through a SCALAR copy: on this clang (ROCm 7.2)
+        // __builtin_bit_cast applied to an ext-vector ELEMENT lvalue (o[c]) reads element 0 whatever c is — the IR of
+        // round 2's form of this loop fed o[0] to all four update.dpp calls, which is what was recorded then as "the
+        // DPP loop is miscompiled" (the ds_bpermute form recorded as "stale" is correct on the present
+        // kernel: 0 of 9.2 M nodes differ, same time — tools/ab/combine_test.py).
 #pragma unroll
-        for (int j = 1; j < LP; ++j) o += HeadVec<DK>::load(base + j * kRec, GS);   // meaningful on lane 0
+        for (int c = 0; c < DK; ++c) {
+          float oc = o[c];
+          oc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, oc), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+          if (LP > 2) oc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, oc), 0x4E, 0xf, 0xf, true));   // lane ^ 2
+          o[c] = oc;
+        }
       }
       const int64_t node = node0 + nb;
       if (part == 0 && node < n) {
@@ -482,7 +482,7 @@ static int launch_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, c
   const int64_t blocks = n_tiles < want ? n_tiles : (want > 0 ? want : 1);
   ProfileScope prof(kProfMhsa, s, n, T);
   hipLaunchKernelGGL((ln_mhsa_split_kernel<D, T, LP, BWD>), dim3((unsigned)blocks, CB), dim3(64 * NW), lds, s, x, ld_n, ld_t, n,
-                     gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, n_tiles, dqkv, y);
+                     gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, n_tiles, dqkv, y, redo_counter());
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }

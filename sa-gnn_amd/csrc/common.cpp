@@ -79,6 +79,23 @@ int cu_count_current() {
   return c;
 }
 
+unsigned int* redo_counter() {
+  static std::mutex mu;
+  static std::map<int, unsigned int*> ctr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  unsigned int*& c = ctr[dev];
+  if (!c) {
+    if (hipMalloc((void**)&c, sizeof(unsigned int)) != hipSuccess) {
+      c = nullptr;
+      return nullptr;
+    }
+    (void)hipMemset(c, 0, sizeof(unsigned int));
+  }
+  return c;
+}
+
 // ---- profiler ---------------------------------------------------------------------------------
 namespace {
 struct ProfRecord {
@@ -154,6 +171,18 @@ extern "C" int sagnn_profile_read(float* ms, int32_t* kind, int64_t* units_a, in
   }
   *n_out = n;
   p.used = 0;
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_range_redo_count(int64_t* count, int reset) {
+  if (!count) return sagnn::fail(SAGNN_ERR_NULL, "count is NULL");
+  unsigned int* c = sagnn::redo_counter();
+  if (!c) return sagnn::fail(SAGNN_ERR_NOMEM, "no device counter");
+  unsigned int v = 0;
+  SAGNN_HIP_TRY(hipDeviceSynchronize());
+  SAGNN_HIP_TRY(hipMemcpy(&v, c, sizeof v, hipMemcpyDeviceToHost));
+  if (reset) SAGNN_HIP_TRY(hipMemset(c, 0, sizeof v));
+  *count = (int64_t)v;
   return SAGNN_OK;
 }
 

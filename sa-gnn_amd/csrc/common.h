@@ -35,6 +35,9 @@ inline int lanes_per_row(int d) {
 // threads and devices (include/sagnn.h: reentrant, no global mutable state visible to callers).
 int ensure_dynamic_lds(const void* kernel, size_t bytes);
 int cu_count_current();   // compute units of the current device (256 on MI355X), cached per device
+// Device counter (one per device, allocated on first use) that the f16 x 2 kernels bump once per tile / chunk they
+// re-evaluate in fp32 because an operand left the split's window (f16_split.h, RANGE): sagnn_range_redo_count reads it.
+unsigned int* redo_counter();
 
 // fusion_mfma.hip
 bool lstm_mfma_supported(int d);

@@ -13,7 +13,10 @@
 //     next to larger neighbours, and wrong for operands that are small as a whole (a gradient row of 1e-9).
 // Callers therefore pass what they split through a RangeTrack — the running max |v| and the running min, over the
 // aligned 4-element segments a lane splits, of the segment's max |v| (all-zero segments aside) — and re-evaluate in
-// fp32 whatever saw |v| >= 32768 or a segment whose max is below 2^-18 (range_bad). What stays on the fast path
+// fp32 whatever saw |v| >= 32768 or a segment whose max is below 2^-18 (range_bad). The segment stands in for the
+// ROW (a row maximum would cost a cross-lane reduction per row): right for operands without structure inside a row
+// (embedding sums, layer-normed rows, weights), wrong for a recurrent h, where saturated gates leave 1e-14 next to
+// 0.9 — h therefore takes the top check only (range_seg4_hi). What stays on the fast path
 // has every element within max(2^-23 |v|, 2^-37) <= 2^-19 x its segment's max of the fp32 value (2^-23 when the
 // segment's max is >= 2^-14). Operands whose scale is arbitrary by nature (gradients: attn_bwd_tail_f16.hip) are
 // brought into the window by an exact power-of-two scale per row instead.
@@ -88,6 +91,12 @@ __device__ __forceinline__ void range_seg(RangeTrack& r, float s) {
 }
 __device__ __forceinline__ void range_seg4(RangeTrack& r, float a, float b, float c, float d) {
   range_seg(r, maxabs_acc(maxabs3(a, b, c), d));
+}
+// the top of the window only — for operands that are bounded below by construction or whose small rows are caught
+// through another operand: a recurrent h (saturated gates leave 1e-14 next to 0.9 in one row; a row of h that is tiny
+// as a whole comes from an x row that is, and that one is caught)
+__device__ __forceinline__ void range_seg4_hi(RangeTrack& r, float a, float b, float c, float d) {
+  r.hi = maxabs_acc(r.hi, maxabs_acc(maxabs3(a, b, c), d));
 }
 __device__ __forceinline__ bool range_bad(const RangeTrack& r) { return r.hi >= kF16Lim || r.lo < kF16LowBits - 1u; }
 

@@ -86,7 +86,8 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
     const float* __restrict__ x, int64_t ld_n, int64_t ld_t, int64_t n, int t, const float* __restrict__ W,
     const float* __restrict__ bias, float forget_bias, const float* __restrict__ drop, float* __restrict__ h_out,
     int64_t ld_h, float* __restrict__ gates_out, float* __restrict__ c_out, int64_t n_tiles,
-    const float* __restrict__ h_init, int64_t ld_hi, const float* __restrict__ c_init, float* __restrict__ c_final) {
+    const float* __restrict__ h_init, int64_t ld_hi, const float* __restrict__ c_init, float* __restrict__ c_final,
+    unsigned int* __restrict__ redo_ctr) {
   constexpr int NW = D / 16;          // waves per workgroup
   constexpr int NT = 64 * NW;         // threads
   constexpr int KSH = D / 32;         // k-steps (of 32) per operand half
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
         const int r = p * RPP + fr;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < rows_valid) v = *reinterpret_cast<const float4*>(h_init + (row0 + r) * ld_hi + fc4);
-        range_seg4(xrng, v.x, v.y, v.z, v.w);
+        range_seg4_hi(xrng, v.x, v.y, v.z, v.w);   // h: top of the window only (f16_split.h)
         write_pieces(Hp, r, fc4, v);
       }
     }
@@ -430,6 +431,7 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, c[bt]), rs_cf, ((bt * 16 + m) * D + hid0) * 4, 0, 0);
     }
     if (redo) {
+      if (tid == 0 && redo_ctr) atomicAdd(redo_ctr, 1u);
       __syncthreads();        // this tile's global stores have left: the slow pass rewrites the same addresses
       // ---- a value outside the split's window went into this tile (or sits in W): the whole tile again as plain fp32
       // fmaf chains, thread per (row, hidden unit), h and c of the tile in LDS. Never taken on sane data.
@@ -502,7 +504,7 @@ int launch_lstm_f16(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t
   const int64_t blocks = n_tiles < want ? n_tiles : want;
   ProfileScope prof(kProfLstm, s, n, t);
   hipLaunchKernelGGL((lstm_fwd_f16_kernel<D, SAVE, DROP>), dim3((unsigned)blocks), dim3(64 * (D / 16)), lds, s, x, ld_n, ld_t,
-                     n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, n_tiles, h_init, ld_hi, c_init, c_final);
+                     n, t, W, b, forget_bias, drop, h, ld_h, gates_out, c_out, n_tiles, h_init, ld_hi, c_init, c_final, redo_counter());
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }

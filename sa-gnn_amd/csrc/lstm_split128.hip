@@ -21,6 +21,8 @@
 //     workspace; with saved cell states (training) it is read from / written to them instead.
 // Output dropout is not offered here (the recurrent h would need a second copy): callers with a mask use
 // the VALU kernel. Reference: model.py:135-146, TF 1.14 BasicLSTMCell (see lstm_f16_kernel.h).
+#include <type_traits>
+
 #include "common.h"
 #include "f16_split.h"
 
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
     const float* __restrict__ x_t, int64_t ld_x, const float* __restrict__ h_prev, int64_t ld_hp,
     const float* c_prev, int64_t ld_cp, const float* __restrict__ W, const float* __restrict__ bias,
     float forget_bias, float* h_out, int64_t ld_h, float* c_out, int64_t ld_c,
-    float* __restrict__ gates_out, int64_t ld_g, int64_t n, int64_t n_tiles) {
+    float* __restrict__ gates_out, int64_t ld_g, int64_t n, int64_t n_tiles, unsigned int* __restrict__ redo_ctr) {
   // c_prev and h_out may be the SAME addresses (the cell state parked in h's next slot): no __restrict__ on them;
   // a lane reads its c before it stores its h.
   constexpr float kL2E = 1.44269504088896340736f;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
   // fill mapping: 32 threads per row (float4 each), 8 rows per pass
   const int fr = tid >> 5, fc4 = (tid & 31) * 4;
   RangeTrack xr = range_init();   // range of what this thread moved into the images of the current tile (f16_split.h, RANGE)
-  auto fill_half = [&](const float* src, int64_t ld, int64_t row0, int rows_valid, int kbase) {
+  auto fill_half = [&](const float* src, int64_t ld, int64_t row0, int rows_valid, int kbase, auto is_h) {
     float4 v[kRows / 8];
 #pragma unroll
     for (int p = 0; p < kRows / 8; ++p) {
@@ -110,7 +112,8 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
 #pragma unroll
     for (int p = 0; p < kRows / 8; ++p) {
       const int r = p * 8 + fr;
-      range_seg4(xr, v[p].x, v[p].y, v[p].z, v[p].w);
+      if constexpr (decltype(is_h)::value) range_seg4_hi(xr, v[p].x, v[p].y, v[p].z, v[p].w);   // h: top of the window only (f16_split.h)
+      else range_seg4(xr, v[p].x, v[p].y, v[p].z, v[p].w);
       const int p0 = head2(v[p].x, v[p].y), p1 = head2(v[p].z, v[p].w);
       const int col = kbase + fc4;
       const int off = r * (K2 * 2) + ((((col >> 3)) ^ (r & 31)) << 4) + ((col >> 2) & 1) * 8;
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
     const int rows_valid = (int)(n - row0 < kRows ? n - row0 : kRows);
     if (tid == 0) flags[par] = 0;   // two tiles (and their barriers) after its last reader
     xr = range_init();
-    fill_half(x_t, ld_x, row0, rows_valid, 0);
-    if (!FIRST) fill_half(h_prev, ld_hp, row0, rows_valid, D);
+    fill_half(x_t, ld_x, row0, rows_valid, 0, std::false_type{});
+    if (!FIRST) fill_half(h_prev, ld_hp, row0, rows_valid, D, std::true_type{});
     lds_barrier();
     if (range_bad(xr)) flags[par] = 1;    // after the barrier that follows the reset; read after the next one
 
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
     lds_barrier();   // every wave has read the images before the next tile's fill
     if (flags[par] | flags[2]) {
       // ---- a value outside the split's window: this lane's rows and units again as fp32 fmaf chains, stored over the fast pass
+      if (tid == 0 && redo_ctr) atomicAdd(redo_ctr, 1u);
       __syncthreads();   // the fast pass's stores have left
 #pragma unroll 1
       for (int bt = 0; bt < kBT; ++bt) {
@@ -247,7 +251,7 @@ static int launch_step(const float* x_t, int64_t ld_x, const float* h_prev, int6
   const int64_t per_slice = cu_count_current() / 2 > 0 ? cu_count_current() / 2 : 1;   // 4 hidden slices share 2 workgroup slots per CU
   const int64_t bx = n_tiles < per_slice ? n_tiles : per_slice;
   hipLaunchKernelGGL((lstm_step128_kernel<SAVE, FIRST>), dim3((unsigned)bx, 4), dim3(256), lds, s, x_t, ld_x, h_prev,
-                     ld_hp, c_prev, ld_cp, W, b, forget_bias, h_out, ld_h, c_out, ld_c, gates_out, ld_g, n, n_tiles);
+                     ld_hp, c_prev, ld_cp, W, b, forget_bias, h_out, ld_h, c_out, ld_c, gates_out, ld_g, n, n_tiles, redo_counter());
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }

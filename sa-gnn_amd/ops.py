@@ -25,6 +25,13 @@ def get_engine() -> str:
     return next(k for k, v in ENGINES.items() if v == code)
 
 
+def range_redo_count(reset: bool = False) -> int:
+    """sagnn_range_redo_count: tiles / chunks the f16 x 2 kernels re-evaluated in fp32 since the last reset."""
+    n = ctypes.c_int64(0)
+    check(_lib.load().sagnn_range_redo_count(ctypes.byref(n), 1 if reset else 0))
+    return int(n.value)
+
+
 class engine:
     """`with ops.engine("f32"): ...` — runs the block under that engine and restores the caller's."""
 

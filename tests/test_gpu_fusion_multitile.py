@@ -42,7 +42,9 @@ def test_lstm_many_tiles_per_block(dev, d, t, n):
     rng = np.random.default_rng(d * 100 + t)
     x = rng.standard_normal((n, t, d)).astype(np.float32)
     p, pd = _params(d, rng, dev)
+    ops.range_redo_count(reset=True)
     got = ops.lstm_fwd(torch.from_numpy(x).to(dev), pd["lstm_W"], pd["lstm_b"], 1.0)
+    assert ops.range_redo_count() == 0, "ordinary data must stay on the matrix-core path (no fp32 redo of a tile)"
     _check(got, O.basic_lstm(x, p["lstm_W"], p["lstm_b"], 1.0), "lstm_fwd")
 
 
@@ -52,8 +54,10 @@ def test_ln_mhsa_mean_many_tiles_per_block(dev, d, t, n):
     rng = np.random.default_rng(d * 100 + t + 1)
     x = rng.standard_normal((n, t, d)).astype(np.float32)
     p, pd = _params(d, rng, dev)
+    ops.range_redo_count(reset=True)
     got = ops.ln_mhsa_mean(torch.from_numpy(x).to(dev), pd["ln_gamma"], pd["ln_beta"], pd["Wq"], pd["bq"], pd["Wk"],
                            pd["bk"], pd["Wv"], pd["bv"], 16)
+    assert ops.range_redo_count() == 0, "ordinary data must stay on the matrix-core path"
     y = O.layer_norm_td(x, p["ln_gamma"], p["ln_beta"])
     want = O.mhsa(y, p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], 16).mean(axis=1)
     _check(got, want, "ln_mhsa_mean")
@@ -66,7 +70,9 @@ def test_interval_fusion_many_tiles_per_block(dev, d, t, n):
     rng = np.random.default_rng(d * 100 + t + 2)
     xs = rng.standard_normal((t, n, d)).astype(np.float32)
     p, pd = _params(d, rng, dev)
+    ops.range_redo_count(reset=True)
     got = ops.interval_fusion(torch.from_numpy(xs).to(dev).permute(1, 0, 2), pd, 16)
+    assert ops.range_redo_count() == 0, "ordinary data must stay on the matrix-core path"
     _check(got, O.interval_fusion(np.ascontiguousarray(xs.transpose(1, 0, 2)), p, 16), "interval_fusion")
 
 
@@ -87,9 +93,12 @@ def test_training_forward_and_backward_many_tiles_per_block(dev, d, t, n):
     (out * torch.tensor(gout, dtype=torch.float64)).sum().backward()
     xd = torch.from_numpy(x).to(dev).requires_grad_(True)
     pd = {k: torch.from_numpy(v).to(dev).requires_grad_(True) for k, v in p.items()}
+    from sa_gnn_amd import ops
+    ops.range_redo_count(reset=True)
     got = ag.interval_fusion(xd, pd, 16)
     _check(got.detach(), out.detach().numpy(), "training forward")
     got.backward(torch.from_numpy(gout).to(dev))
+    assert ops.range_redo_count() == 0, "ordinary data and O(1) gradients must stay on the matrix-core path"
     for name, a, b in [("dx", xd.grad, tx.grad)] + [("d" + k, pd[k].grad, tp[k].grad) for k in p]:
         a, b = a.cpu().numpy().astype(np.float64), b.numpy()
         # parameter gradients are sums over n*t rows of O(1) terms. Some are analytically ~0 (a key
@@ -175,7 +184,9 @@ def test_lstm_inputs_beyond_the_f16_range(dev, d, t, n):
     x[7] *= 1e-7                                   # denormal heads: the residual piece carries the value
     x[200 % n, :, :] *= 1e-30
     p, pd = _params(d, rng, dev)
+    ops.range_redo_count(reset=True)
     got = ops.lstm_fwd(torch.from_numpy(x).to(dev), pd["lstm_W"], pd["lstm_b"], 1.0)
+    assert ops.range_redo_count() >= 4                      # the tiles that hold those rows went through the fp32 pass
     want = O.basic_lstm(x.astype(np.float64), p["lstm_W"].astype(np.float64), p["lstm_b"].astype(np.float64), 1.0)
     assert np.isfinite(got.cpu().numpy()).all()
     _check(got, want.astype(np.float32), "lstm_fwd beyond the f16 range")

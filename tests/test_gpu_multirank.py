@@ -1,9 +1,9 @@
 """GPU rehearsal of the N > 1 pipeline on ONE GPU: two ranks share cuda:0, every kernel is the real
 HIP one, only the transport is gloo (host-staged) instead of RCCL. The fused embeddings must be
-identical to the single-process run over the same four interval graphs."""
+identical to the single-process run over the same four interval graphs. Every N > 1 run goes through the entry the
+driver uses — `python bench.py --gpus N ...` from a bare shell — which starts its own ranks (bench.self_launch)."""
 import json
 import os
-import socket
 import subprocess
 import sys
 
@@ -23,17 +23,10 @@ def _run(cmd):
     return json.loads(line[0])
 
 
-def _port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 def test_two_ranks_match_single_process():
     common = ["--steps", "1", "--warmup", "1", "--scale", "0.004", "--no-cpu-baseline"]
     one = _run([sys.executable, "bench.py", "--intervals", "4"] + common)
-    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                "--master-addr", "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "2",
+    two = _run([sys.executable, "bench.py", "--gpus", "2",
                 "--dist-backend", "gloo", "--intervals", "4"] + common)
     assert one["config"]["intervals_total"] == two["config"]["intervals_total"] == 4
     assert two["n_gpus"] == 2 and two["config"]["exchange"] == "alltoall"
@@ -47,8 +40,7 @@ def test_three_ranks_round_wise_fusion_matches_single_process():
     """Three ranks, six intervals: two exchange rounds, the LSTM continued across them."""
     common = ["--steps", "1", "--warmup", "1", "--scale", "0.003", "--no-cpu-baseline"]
     one = _run([sys.executable, "bench.py", "--intervals", "6"] + common)
-    three = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
-                  "--master-addr", "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "3",
+    three = _run([sys.executable, "bench.py", "--gpus", "3",
                   "--dist-backend", "gloo", "--intervals", "6"] + common)
     assert one["config"]["intervals_total"] == three["config"]["intervals_total"] == 6
     assert one["final_abs_mean"] == three["final_abs_mean"]
@@ -60,8 +52,7 @@ def test_four_ranks_match_single_process():
     per rank, four exchange rounds, T = 16 fusion) at a reduced scale."""
     common = ["--steps", "1", "--warmup", "1", "--scale", "0.002", "--no-cpu-baseline"]
     one = _run([sys.executable, "bench.py"] + common)
-    four = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
-                 "--master-addr", "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "4",
+    four = _run([sys.executable, "bench.py", "--gpus", "4",
                  "--dist-backend", "gloo"] + common)
     assert one["scaling"] == four["scaling"] == "strong"
     assert one["config"]["intervals_total"] == four["config"]["intervals_total"] == 16
@@ -77,8 +68,7 @@ def test_fewer_intervals_than_ranks_split_rows_match_single_process():
     T = 5 on 8 ranks runs on the CPU in tests/test_parallel.py.)"""
     common = ["--workload", "gowalla-shaped", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
     one = _run([sys.executable, "bench.py"] + common)
-    six = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
-                "--master-addr", "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "4",
+    six = _run([sys.executable, "bench.py", "--gpus", "4",
                 "--dist-backend", "gloo"] + common)
     assert one["config"]["intervals_total"] == six["config"]["intervals_total"] == 3
     assert "T < world" in six["config"]["partitioning"]
@@ -96,8 +86,7 @@ def test_rccl_two_gpus_smoke():
         pytest.skip("needs 2 GPUs (RCCL over xGMI)")
     common = ["--steps", "1", "--warmup", "1", "--scale", "0.004", "--no-cpu-baseline", "--intervals", "4"]
     one = _run([sys.executable, "bench.py"] + common)
-    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                "--master-addr", "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "2"] + common)
+    two = _run([sys.executable, "bench.py", "--gpus", "2"] + common)
     assert one["final_abs_mean"] == two["final_abs_mean"]
     assert one["final_position_checksum"] == two["final_position_checksum"]
 
@@ -108,8 +97,7 @@ def test_two_rank_training_step_matches_single_process():
     embeddings of both runs agree (weight-gradient sums use float atomics: not bit for bit)."""
     common = ["--stages", "train", "--steps", "2", "--warmup", "0", "--scale", "0.002", "--no-cpu-baseline", "--intervals", "4"]
     one = _run([sys.executable, "bench.py"] + common)
-    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                "--master-addr", "127.0.0.1", "--master-port", str(_port()), "bench.py", "--gpus", "2",
+    two = _run([sys.executable, "bench.py", "--gpus", "2",
                 "--dist-backend", "gloo"] + common)
     for a_, b_ in zip(one["final_abs_mean"] + one["final_position_checksum"], two["final_abs_mean"] + two["final_position_checksum"]):
         assert abs(a_ - b_) <= 2e-5 * abs(a_), (one["final_abs_mean"], two["final_abs_mean"])

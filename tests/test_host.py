@@ -4,6 +4,7 @@ host mirror (Params, DataHandler contract, synthetic writer). No GPU compute is 
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -297,3 +298,36 @@ def test_adam_multi_batches_skip_empty_tensors_without_stepping_any_twice():
     lib = _lib.load()
     assert lib.sagnn_adam_multi_f32(0, None, None, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 1, None) == 0
 
+
+
+def test_bench_starts_its_own_ranks_when_started_bare(monkeypatch):
+    """`python bench.py --gpus N` is how the driver starts every bench (BENCH_rNN.json `cmd`): with N > 1 and no
+    WORLD_SIZE in the environment the process must start N ranks under torch.distributed.run as a CHILD (before any
+    GPU call), pass its own arguments through and exit with the child's code."""
+    import subprocess
+    import bench
+    cmd = bench.launch_command(8, ["--gpus", "8", "--steps", "3", "--warmup", "1"], 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    script = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[script + 1:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    seen = {}
+
+    def fake_run(c, env=None, **kw):
+        seen["cmd"], seen["env"] = c, env
+        return subprocess.CompletedProcess(c, 7)
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--dist-backend", "gloo", "--scale", "0.004", "--intervals", "4"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7                                       # the launcher's exit code is the parent's
+    assert seen["cmd"][-8:] == ["--gpus", "2", "--dist-backend", "gloo", "--scale", "0.004", "--intervals", "4"]
+    assert "--nproc-per-node=2" in seen["cmd"] and seen["env"]["MASTER_ADDR"] == "127.0.0.1"
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher (WORLD_SIZE set) a rank count that disagrees with --gpus is still refused
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "agree" in str(e.value.code)
