@@ -198,6 +198,16 @@ def main():
         local_launch_edges += pu.nnz + pi.nnz
         log(f"rank {rank}: interval {k}: nnz user-side/item-side={pu.nnz}/{pi.nnz} max_deg={pu.info.max_degree}/{pi.info.max_degree} "
             f"long rows {pu.info.n_long_rows}/{pi.info.n_long_rows} ({time.time() - t0:.1f}s)")
+    # dataset-sized graphs: the T intervals of a layer in ONE launch (sagnn_gnn_stack_f32); the embeddings then live in
+    # [T, N, d] tensors, as the model's parameters do
+    use_batch = (not synthetic_wl) and world == 1 and len(plans) == T and T > 0
+    batch = None
+    if use_batch:
+        batch = ops.SpmmBatch([pp[0] for pp in plans], [pp[1] for pp in plans])
+        emb_u, emb_i = torch.stack([e[0] for e in emb]), torch.stack([e[1] for e in emb])
+        emb = [(emb_u[k], emb_i[k]) for k in range(T)]
+        scr_bu = torch.empty((2, T, U, d), device=dev) if L > 1 else None
+        scr_bi = torch.empty((2, T, I, d), device=dev) if L > 1 else None
     torch.cuda.empty_cache()
     from sa_gnn_amd.model import random_fusion_params
     prm = [random_fusion_params(d, dev, seed) for seed in (7, 8)]       # users, items
@@ -230,6 +240,9 @@ def main():
             if post:
                 ex_u.post(acc_u.to(comm_dev))
                 ex_i.post(acc_i.to(comm_dev))
+            return
+        if use_batch:
+            ops.gnn_stack(batch, emb_u, emb_i, L, 0.5, out_u, out_i, scr_bu, scr_bi)
             return
         for j in range(t_loc):
             ops.gnn_interval(plans[j][0], plans[j][1], emb[j][0], emb[j][1], L, 0.5, out_u[j], out_i[j], scr_u, scr_i)
@@ -305,7 +318,10 @@ def main():
         def step():                                       # noqa: F811  (training step replaces the forward step)
             for v in leaves.values():
                 v.grad = None
-            us, its = ag.gnn_stack(leaves["uEmbed"], leaves["iEmbed"], pl_u, pl_i, L, 0.5)      # [T_local, N, d] slabs, no stack copy
+            if use_batch:
+                us, its = ag.gnn_stack(leaves["uEmbed"], leaves["iEmbed"], batch, None, L, 0.5)
+            else:
+                us, its = ag.gnn_stack(leaves["uEmbed"], leaves["iEmbed"], pl_u, pl_i, L, 0.5)  # [T_local, N, d] slabs, no stack copy
             finals, loss = [], 0.0
             for xs, n_rows, p in ((us, U, prm[0]), (its, I, prm[1])):
                 if world > 1:
@@ -461,6 +477,8 @@ def main():
                    "embed_dim": d, "gnn_layers": L, "heads": heads, "stages": a.stages,
                    "exchange": a.exchange if world > 1 else "none", "scale": a.scale, "item_zipf_s": a.zipf,
                    "launch": "hipGraph replay" if graph_mode else "eager",
+                   "spmm_launches": ("one per layer for all intervals and both directions (sagnn_gnn_stack_f32)" if use_batch
+                                     else "one per interval, layer and direction (sagnn_gnn_interval_f32)"),
                    "fusion_gemm": {"f16x2": "f16x2 (two round-to-nearest f16 pieces, three piece products, fp32 accumulation; "
                                             "the SpMM itself is plain fp32)",
                                    "f32": "f32 MFMA (v_mfma_f32_32x32x2_f32: an fp32 fmaf chain)",

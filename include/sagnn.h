@@ -228,6 +228,39 @@ int sagnn_gnn_interval_bwd_f32(const sagnn_spmm_plan* plan_user, const sagnn_spm
                                void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * The WHOLE loop over k of model.py:118-129 in one launch per layer. The reference's loop body is independent per
+ * interval, so a layer of the stack is 2 T independent SpMMs (T with rows = users, T with rows = items); on
+ * dataset-sized graphs (tens of thousands of rows) each is a launch of a few microseconds and the stack is bound by
+ * its 2 T L launches (+ as many fix-ups). A batch object ties the T interval plans together: a block of the batched
+ * kernel finds (direction, interval, row block) by division, every per-interval operand is a SLAB — interval k's
+ * [N, d] matrix starts `slab` elements after interval k-1's, rows `ld` apart — so u0 [T, U, d] is (ld = d,
+ * slab = U d) and a column of the [N, T, d] tensor the fusion reads is (ld = T d, slab = d). One row launch and (if
+ * any interval has long rows) ONE fix-up launch per layer: Amazon-shaped T = 5, L = 3: 60 launches -> 6.
+ *
+ * sagnn_spmm_batch_create keeps the plans' device CSR pointers: the plans must outlive the batch. Every interval must
+ * have the same user / item counts. Workspace: sagnn_spmm_batch_workspace_bytes (partial sums of all long-row chunks).
+ * sagnn_gnn_stack_f32: sagnn_gnn_interval_ex_f32 for all intervals; scratch_u [2, T, U, d], scratch_i [2, T, I, d]
+ *   (NULL when n_layers <= 1); mask_u [T, n_layers, U, d/4] / mask_i [T, n_layers, I, d/4] bytes (both or neither).
+ * sagnn_gnn_stack_bwd_f32: sagnn_gnn_interval_bwd_f32 for all intervals; scratch_u [4, T, U, d], scratch_i [4, T, I, d];
+ *   `batch` must tie the ADJOINT plans (the adjoint contract above, per interval).
+ * -------------------------------------------------------------------------------- */
+typedef struct sagnn_spmm_batch sagnn_spmm_batch;
+int sagnn_spmm_batch_create(const sagnn_spmm_plan* const* plans_user, const sagnn_spmm_plan* const* plans_item,
+                            int n_intervals, sagnn_spmm_batch** batch_out);
+int sagnn_spmm_batch_destroy(sagnn_spmm_batch* batch);
+size_t sagnn_spmm_batch_workspace_bytes(const sagnn_spmm_batch* batch, int d);
+int sagnn_gnn_stack_f32(const sagnn_spmm_batch* batch, const float* u0, int64_t ld_u0, int64_t slab_u0,
+                        const float* i0, int64_t ld_i0, int64_t slab_i0, int d, int n_layers, float leaky,
+                        float* scratch_u, float* scratch_i, float* user_out, int64_t ld_uo, int64_t slab_uo,
+                        float* item_out, int64_t ld_io, int64_t slab_io, uint8_t* mask_u, uint8_t* mask_i,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int sagnn_gnn_stack_bwd_f32(const sagnn_spmm_batch* batch, const float* G_u, int64_t ld_gu, int64_t slab_gu,
+                            const float* G_i, int64_t ld_gi, int64_t slab_gi, int d, int n_layers, float leaky,
+                            const uint8_t* mask_u, const uint8_t* mask_i, float* scratch_u, float* scratch_i,
+                            float* grad_u0, int64_t ld_du, int64_t slab_du, float* grad_i0, int64_t ld_di,
+                            int64_t slab_di, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Interval fusion (model.py:135-155). x[node, interval, :] is read at
  * x + node*ld_n + interval*ld_t (elements): [n, t, d] storage is ld_t = d, ld_n >= t*d (what
  * tf.stack + tf.transpose produce, model.py:131-134); [t, n, d] storage is ld_n = d,

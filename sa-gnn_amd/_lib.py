@@ -64,6 +64,15 @@ SIGNATURES = {
     "sagnn_gnn_interval_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
                                            c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                            c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "sagnn_spmm_batch_create": (c_int, [c_void_p, c_void_p, c_int, POINTER(c_void_p)]),
+    "sagnn_spmm_batch_destroy": (c_int, [c_void_p]),
+    "sagnn_spmm_batch_workspace_bytes": (c_size_t, [c_void_p, c_int]),
+    "sagnn_gnn_stack_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_float,
+                                    c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p,
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    "sagnn_gnn_stack_bwd_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int, c_int,
+                                        c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
+                                        c_void_p, c_int64, c_int64, c_void_p, c_size_t, c_void_p]),
     "sagnn_gnn_interval_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                        c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_int64,
                                        c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),

@@ -55,8 +55,9 @@ def gnn_interval(u0, i0, plan_user, plan_item, n_layers: int, leaky: float):
 class GnnStackFn(torch.autograd.Function):
     """(uEmbed [T, U, d], iEmbed [T, I, d]) -> (user slab [T, U, d], item slab [T, I, d]): the whole loop of
     model.py:118-129 as ONE autograd node. Interval outputs are written straight into the slabs the fusion reads
-    as [N, T, d] views (no torch.stack copy), and the backward hands each interval's gradient slice — whatever
-    its row stride — to sagnn_gnn_interval_bwd_f32, writing the embedding gradients in place."""
+    as [N, T, d] views (no torch.stack copy). With an ops.SpmmBatch the loop over k happens INSIDE the launches
+    (one per layer, sagnn_gnn_stack_f32 / _bwd_f32); with plan lists every interval takes its own 2 L launches
+    (sagnn_gnn_interval_ex_f32: graphs whose T-fold scratch would not fit)."""
 
     @staticmethod
     def forward(ctx, u_embed, i_embed, plans_user, plans_item, n_layers, leaky):
@@ -68,11 +69,15 @@ class GnnStackFn(torch.autograd.Function):
         out_i = torch.empty((T, I, d), dtype=torch.float32, device=dev)
         mask_u = torch.empty((T, n_layers, U, d // 4), dtype=torch.uint8, device=dev)
         mask_i = torch.empty((T, n_layers, I, d // 4), dtype=torch.uint8, device=dev)
-        scr_u = torch.empty((2, U, d), dtype=torch.float32, device=dev) if n_layers > 1 else None
-        scr_i = torch.empty((2, I, d), dtype=torch.float32, device=dev) if n_layers > 1 else None
-        for k in range(T):
-            ops.gnn_interval(plans_user[k], plans_item[k], ue[k], ie[k], n_layers, leaky, out_u[k], out_i[k], scr_u, scr_i,
-                             mask_u=mask_u[k], mask_i=mask_i[k])
+        if isinstance(plans_user, ops.SpmmBatch):
+            ops.gnn_stack(plans_user, ue if ue.stride(2) == 1 else ue.contiguous(), ie if ie.stride(2) == 1 else ie.contiguous(),
+                          n_layers, leaky, out_u, out_i, mask_u=mask_u, mask_i=mask_i)
+        else:
+            scr_u = torch.empty((2, U, d), dtype=torch.float32, device=dev) if n_layers > 1 else None
+            scr_i = torch.empty((2, I, d), dtype=torch.float32, device=dev) if n_layers > 1 else None
+            for k in range(T):
+                ops.gnn_interval(plans_user[k], plans_item[k], ue[k], ie[k], n_layers, leaky, out_u[k], out_i[k], scr_u, scr_i,
+                                 mask_u=mask_u[k], mask_i=mask_i[k])
         ctx.save_for_backward(mask_u, mask_i)
         ctx.plans = (plans_user, plans_item)
         ctx.cfg = (n_layers, leaky)
@@ -95,6 +100,9 @@ class GnnStackFn(torch.autograd.Function):
             g_item = g_item.contiguous()
         du = torch.empty((T, U, d), dtype=torch.float32, device=dev)
         di = torch.empty((T, I, d), dtype=torch.float32, device=dev)
+        if isinstance(plans_user, ops.SpmmBatch):
+            ops.gnn_stack_bwd(plans_user, g_user, g_item, n_layers, leaky, mask_u, mask_i, du, di)
+            return du, di, None, None, None, None
         scr_u = torch.empty((4, U, d), dtype=torch.float32, device=dev)
         scr_i = torch.empty((4, I, d), dtype=torch.float32, device=dev)
         for k in range(T):
@@ -104,6 +112,7 @@ class GnnStackFn(torch.autograd.Function):
 
 
 def gnn_stack(u_embed, i_embed, plans_user, plans_item, n_layers: int, leaky: float):
+    """plans_user: a list of T ops.SpmmPlan (with plans_item the matching list) or an ops.SpmmBatch (plans_item None)."""
     return GnnStackFn.apply(u_embed, i_embed, plans_user, plans_item, n_layers, leaky)
 
 

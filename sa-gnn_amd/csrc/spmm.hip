@@ -156,6 +156,26 @@ __global__ void mask_scale_kernel(const float* __restrict__ g, int64_t ldg, cons
   st4(gm + row * ldgm + 4 * l, z);
 }
 
+// the same for interval blockIdx.y of a slab
+__global__ void mask_scale_batch_kernel(const float* __restrict__ g, int64_t ldg, int64_t s_g, const uint8_t* __restrict__ mask,
+                                        int64_t s_mask, int mask_stride, float slope, float* __restrict__ gm, int64_t ldgm,
+                                        int64_t s_gm, int64_t n_rows, int d) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lpr = d >> 2;
+  if (i >= n_rows * lpr) return;
+  const int64_t k = blockIdx.y;
+  const int64_t row = i / lpr;
+  const int l = (int)(i - row * lpr);
+  const float4 v = ld4(g + k * s_g + row * ldg + 4 * l);
+  const unsigned bits = mask[k * s_mask + row * mask_stride + l];
+  float4 z;
+  z.x = (bits & 1u) ? v.x : slope * v.x;
+  z.y = (bits & 2u) ? v.y : slope * v.y;
+  z.z = (bits & 4u) ? v.z : slope * v.z;
+  z.w = (bits & 8u) ? v.w : slope * v.w;
+  st4(gm + k * s_gm + row * ldgm + 4 * l, z);
+}
+
 // Whole wave sums X[idx[e], :] for e in [e0, e1): G neighbour rows per load instruction.
 // IDENT: the "index" of edge e is e itself (fix-up pass over the partial-sum workspace).
 // Returns the total in every lane-group (cross-group xor reduction).
@@ -198,33 +218,17 @@ __device__ __forceinline__ float4 wave_row_sum(const int32_t* __restrict__ colid
   return acc;
 }
 
-// One launch covers the long-row chunks (first `chunk_blocks` blocks, heaviest work first)
-// and the row blocks (remaining blocks).
+// A wave's share of the row blocks: RPW consecutive rows starting at row0 (short rows by lane groups, medium rows by
+// the whole wave; long rows belong to the chunk waves + fix-up).
 template <int LPR, int RPW>
-__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
-    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
-    const float* __restrict__ X, int64_t ldx, int d, int64_t n_rows, int short_t, int long_t,
-    const int32_t* __restrict__ chunk_e0, const int32_t* __restrict__ chunk_e1, int64_t n_chunks,
-    int chunk_blocks, float* __restrict__ partial, Epilogue ep) {
+__device__ __forceinline__ void rows_wave(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                          const float* __restrict__ X, int64_t ldx, int d, int64_t n_rows, int64_t row0,
+                                          int short_t, int long_t, const Epilogue& ep, int lane) {
   constexpr int G = kWave / LPR;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
   const int grp = lane / LPR;
   const int sub = lane % LPR;
   const int col = 4 * sub;
   const bool lane_on = col < d;
-
-  if ((int)blockIdx.x < chunk_blocks) {
-    const int64_t ci = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-    if (ci >= n_chunks) return;
-    const float4 s =
-        wave_row_sum<LPR, false>(colidx, chunk_e0[ci], chunk_e1[ci], X, ldx, lane, grp, col, lane_on);
-    if (grp == 0 && lane_on) st4(partial + ci * (int64_t)d + col, s);
-    return;
-  }
-
-  const int64_t row0 = ((int64_t)(blockIdx.x - chunk_blocks) * kWavesPerBlock + wave) * RPW;
-  if (row0 >= n_rows) return;
   const int nr = (int)min((int64_t)RPW, n_rows - row0);
   // lane l (l <= nr) holds rowptr[row0 + l]; lanes beyond replicate the last entry (degree 0).
   const int rp = rowptr[row0 + min(lane, nr)];
@@ -296,6 +300,34 @@ __global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
   }
 }
 
+// One launch covers the long-row chunks (first `chunk_blocks` blocks, heaviest work first)
+// and the row blocks (remaining blocks).
+template <int LPR, int RPW>
+__global__ __launch_bounds__(kBlock) void spmm_rows_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+    const float* __restrict__ X, int64_t ldx, int d, int64_t n_rows, int short_t, int long_t,
+    const int32_t* __restrict__ chunk_e0, const int32_t* __restrict__ chunk_e1, int64_t n_chunks,
+    int chunk_blocks, float* __restrict__ partial, Epilogue ep) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+
+  if ((int)blockIdx.x < chunk_blocks) {
+    const int grp = lane / LPR;
+    const int col = 4 * (lane % LPR);
+    const bool lane_on = col < d;
+    const int64_t ci = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (ci >= n_chunks) return;
+    const float4 s =
+        wave_row_sum<LPR, false>(colidx, chunk_e0[ci], chunk_e1[ci], X, ldx, lane, grp, col, lane_on);
+    if (grp == 0 && lane_on) st4(partial + ci * (int64_t)d + col, s);
+    return;
+  }
+
+  const int64_t row0 = ((int64_t)(blockIdx.x - chunk_blocks) * kWavesPerBlock + wave) * RPW;
+  if (row0 >= n_rows) return;
+  rows_wave<LPR, RPW>(rowptr, colidx, X, ldx, d, n_rows, row0, short_t, long_t, ep, lane);
+}
+
 // Fix-up for long rows: add the partial sums of a row in chunk order, then the epilogue.
 template <int LPR>
 __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(const int32_t* __restrict__ long_row,
@@ -312,6 +344,101 @@ __global__ __launch_bounds__(kBlock) void spmm_fixup_kernel(const int32_t* __res
   if (li >= n_long) return;
   const float4 s = wave_row_sum<LPR, true>(nullptr, long_slot[li], long_slot[li + 1], partial, d,
                                            lane, grp, col, lane_on);
+  if (grp == 0 && lane_on) finish_row(ep, long_row[li], col, s);
+}
+
+
+// ---- all T intervals of a layer, both directions, in ONE launch (dataset-sized graphs) ----------------------------
+// The reference's loop over k (model.py:118-129) is independent per interval, so a layer of the stack is 2 T
+// independent SpMMs: T with rows = users, T with rows = items. Segment s of a batch is (direction s / T, interval
+// s % T); all segments of a direction have the same row count, so a row block finds its segment by division. The
+// per-interval operands are slabs of [T, N, d] tensors (or columns of [N, T, d] ones): every pointer of the epilogue
+// carries a slab stride, and segment (dir, k) works on base + k * stride — nothing per-call lives in device memory.
+struct SegMeta {
+  const int32_t* rowptr;
+  const int32_t* colidx;
+  int32_t short_t, long_t;
+};
+struct DirArgs {
+  const float* X;
+  int64_t ldx, s_X;
+  Epilogue ep;
+  // slab strides (elements; bytes for the masks) of ep's pointers
+  int64_t s_res, s_acc_in, s_out, s_acc_out, s_mask_out, s_mask_in, s_out2, s_acc_in2;
+};
+struct BatchGeom {
+  int32_t T;
+  int32_t chunk_blocks;          // blocks [0, chunk_blocks): long-row chunks of every segment
+  int32_t blocks_u, blocks_i;    // row blocks per user / item segment
+  int32_t rows_u, rows_i;
+};
+
+__device__ __forceinline__ Epilogue seg_epilogue(const DirArgs& a, int k) {
+  Epilogue e = a.ep;
+  if (e.residual) e.residual += (int64_t)k * a.s_res;
+  if (e.acc_in) e.acc_in += (int64_t)k * a.s_acc_in;
+  if (e.out) e.out += (int64_t)k * a.s_out;
+  if (e.acc_out) e.acc_out += (int64_t)k * a.s_acc_out;
+  if (e.mask_out) e.mask_out += (int64_t)k * a.s_mask_out;
+  if (e.mask_in) e.mask_in += (int64_t)k * a.s_mask_in;
+  if (e.out2) e.out2 += (int64_t)k * a.s_out2;
+  if (e.acc_in2) e.acc_in2 += (int64_t)k * a.s_acc_in2;
+  return e;
+}
+
+template <int LPR, int RPW>
+__global__ __launch_bounds__(kBlock) void spmm_rows_batch_kernel(const SegMeta* __restrict__ meta, BatchGeom g,
+                                                                const int32_t* __restrict__ chunk_e0,
+                                                                const int32_t* __restrict__ chunk_e1,
+                                                                const int32_t* __restrict__ chunk_seg, int64_t n_chunks,
+                                                                float* __restrict__ partial, int d, DirArgs au, DirArgs ai) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  if ((int)blockIdx.x < g.chunk_blocks) {
+    const int grp = lane / LPR;
+    const int col = 4 * (lane % LPR);
+    const bool lane_on = col < d;
+    const int64_t ci = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (ci >= n_chunks) return;
+    const int seg = __builtin_amdgcn_readfirstlane(chunk_seg[ci]);
+    const int dir = seg >= g.T, k = seg - dir * g.T;
+    const DirArgs& a = dir ? ai : au;
+    const float4 s = wave_row_sum<LPR, false>(meta[seg].colidx, chunk_e0[ci], chunk_e1[ci], a.X + (int64_t)k * a.s_X, a.ldx,
+                                              lane, grp, col, lane_on);
+    if (grp == 0 && lane_on) st4(partial + ci * (int64_t)d + col, s);
+    return;
+  }
+  int rb = (int)blockIdx.x - g.chunk_blocks;
+  const int dir = rb >= g.T * g.blocks_u;
+  if (dir) rb -= g.T * g.blocks_u;
+  const int per = dir ? g.blocks_i : g.blocks_u;
+  const int k = rb / per;
+  const int64_t n_rows = dir ? g.rows_i : g.rows_u;
+  const int64_t row0 = ((int64_t)(rb - k * per) * kWavesPerBlock + wave) * RPW;
+  if (row0 >= n_rows) return;
+  const SegMeta m = meta[dir * g.T + k];
+  const DirArgs& a = dir ? ai : au;
+  const Epilogue ep = seg_epilogue(a, k);
+  rows_wave<LPR, RPW>(m.rowptr, m.colidx, a.X + (int64_t)k * a.s_X, a.ldx, d, n_rows, row0, m.short_t, m.long_t, ep, lane);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void spmm_fixup_batch_kernel(const int32_t* __restrict__ long_row,
+                                                                 const int32_t* __restrict__ long_slot,
+                                                                 const int32_t* __restrict__ long_seg, int64_t n_long,
+                                                                 const float* __restrict__ partial, int d, int T,
+                                                                 DirArgs au, DirArgs ai) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int grp = lane / LPR;
+  const int col = 4 * (lane % LPR);
+  const bool lane_on = col < d;
+  const int64_t li = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (li >= n_long) return;
+  const int seg = __builtin_amdgcn_readfirstlane(long_seg[li]);
+  const int dir = seg >= T, k = seg - dir * T;
+  const Epilogue ep = seg_epilogue(dir ? ai : au, k);
+  const float4 s = wave_row_sum<LPR, true>(nullptr, long_slot[li], long_slot[li + 1], partial, d, lane, grp, col, lane_on);
   if (grp == 0 && lane_on) finish_row(ep, long_row[li], col, s);
 }
 
@@ -763,6 +890,319 @@ extern "C" int sagnn_gnn_interval_bwd_f32(const sagnn_spmm_plan* plan_user, cons
     ld_gun = eu.ld_acc_out;
     gi_next = ei.acc_out;
     ld_gin = ei.ld_acc_out;
+    cur ^= 1;
+  }
+  return SAGNN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Batch over the T intervals: one launch per LAYER of the stack (+ one fix-up launch)
+// ------------------------------------------------------------------------------------------
+struct sagnn_spmm_batch {
+  int T = 0;
+  int64_t U = 0, I = 0;
+  int64_t n_chunks = 0, n_long = 0, nnz = 0;
+  // device: [SegMeta x 2T] and [chunk_e0 | chunk_e1 | chunk_seg | long_row | long_seg | long_slot (+1)]
+  SegMeta* d_meta = nullptr;
+  int32_t* d_ints = nullptr;
+  const int32_t *d_chunk_e0 = nullptr, *d_chunk_e1 = nullptr, *d_chunk_seg = nullptr, *d_long_row = nullptr,
+                *d_long_seg = nullptr, *d_long_slot = nullptr;
+};
+
+extern "C" int sagnn_spmm_batch_create(const sagnn_spmm_plan* const* plans_user, const sagnn_spmm_plan* const* plans_item,
+                                       int n_intervals, sagnn_spmm_batch** batch_out) {
+  if (!batch_out) return sagnn::fail(SAGNN_ERR_NULL, "batch_out is NULL");
+  *batch_out = nullptr;
+  if (!plans_user || !plans_item) return sagnn::fail(SAGNN_ERR_NULL, "plan table is NULL");
+  if (n_intervals < 1 || n_intervals > 4096) return sagnn::fail(SAGNN_ERR_ARG, "n_intervals = %d", n_intervals);
+  const int T = n_intervals;
+  for (int k = 0; k < T; ++k) {
+    if (int rc = check_interval_plans(plans_user[k], plans_item[k])) return rc;
+    if (!plans_user[k]->info.on_device || !plans_item[k]->info.on_device)
+      return sagnn::fail(SAGNN_ERR_ARG, "interval %d: plan was built host-only", k);
+    if (plans_user[k]->info.n_rows != plans_user[0]->info.n_rows || plans_item[k]->info.n_rows != plans_item[0]->info.n_rows)
+      return sagnn::fail(SAGNN_ERR_ARG, "interval %d: every interval must have the same user / item counts", k);
+  }
+  sagnn_spmm_batch* b = new (std::nothrow) sagnn_spmm_batch();
+  if (!b) return sagnn::fail(SAGNN_ERR_NOMEM, "out of host memory");
+  b->T = T;
+  b->U = plans_user[0]->info.n_rows;
+  b->I = plans_item[0]->info.n_rows;
+  std::vector<SegMeta> meta(2 * (size_t)T);
+  std::vector<int32_t> ce0, ce1, cseg, lrow, lseg, lslot;
+  try {
+    for (int s = 0; s < 2 * T; ++s) {
+      const sagnn_spmm_plan* p = s < T ? plans_user[s] : plans_item[s - T];
+      meta[s] = SegMeta{p->d_rowptr, p->d_colidx, p->info.short_thresh, p->info.long_thresh};
+      const int32_t coff = (int32_t)ce0.size();
+      ce0.insert(ce0.end(), p->chunk_e0.begin(), p->chunk_e0.end());
+      ce1.insert(ce1.end(), p->chunk_e1.begin(), p->chunk_e1.end());
+      cseg.insert(cseg.end(), p->chunk_e0.size(), (int32_t)s);
+      for (size_t j = 0; j < p->long_row.size(); ++j) {
+        lrow.push_back(p->long_row[j]);
+        lseg.push_back((int32_t)s);
+        lslot.push_back(coff + p->long_slot[j]);
+      }
+      b->nnz += p->info.nnz;
+    }
+    lslot.push_back((int32_t)ce0.size());
+  } catch (const std::bad_alloc&) {
+    delete b;
+    return sagnn::fail(SAGNN_ERR_NOMEM, "out of host memory building the batch tables");
+  }
+  if (ce0.size() > (size_t)INT32_MAX - 256) {
+    delete b;
+    return sagnn::fail(SAGNN_ERR_ARG, "too many long-row chunks for one batch");
+  }
+  b->n_chunks = (int64_t)ce0.size();
+  b->n_long = (int64_t)lrow.size();
+  hipError_t e = hipMalloc((void**)&b->d_meta, meta.size() * sizeof(SegMeta));
+  if (e == hipSuccess) e = hipMemcpy(b->d_meta, meta.data(), meta.size() * sizeof(SegMeta), hipMemcpyHostToDevice);
+  if (e == hipSuccess && b->n_chunks > 0) {
+    const size_t nck = ce0.size(), nl = lrow.size();
+    std::vector<int32_t> host;
+    host.reserve(3 * nck + 3 * nl + 1);
+    host.insert(host.end(), ce0.begin(), ce0.end());
+    host.insert(host.end(), ce1.begin(), ce1.end());
+    host.insert(host.end(), cseg.begin(), cseg.end());
+    host.insert(host.end(), lrow.begin(), lrow.end());
+    host.insert(host.end(), lseg.begin(), lseg.end());
+    host.insert(host.end(), lslot.begin(), lslot.end());
+    e = hipMalloc((void**)&b->d_ints, host.size() * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemcpy(b->d_ints, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    b->d_chunk_e0 = b->d_ints;
+    b->d_chunk_e1 = b->d_ints + nck;
+    b->d_chunk_seg = b->d_ints + 2 * nck;
+    b->d_long_row = b->d_ints + 3 * nck;
+    b->d_long_seg = b->d_ints + 3 * nck + nl;
+    b->d_long_slot = b->d_ints + 3 * nck + 2 * nl;
+  }
+  if (e != hipSuccess) {
+    if (b->d_meta) (void)hipFree(b->d_meta);
+    if (b->d_ints) (void)hipFree(b->d_ints);
+    delete b;
+    return sagnn::hip_fail(e, "batch tables (hipMalloc / hipMemcpy)");
+  }
+  *batch_out = b;
+  return SAGNN_OK;
+}
+
+extern "C" int sagnn_spmm_batch_destroy(sagnn_spmm_batch* b) {
+  if (!b) return SAGNN_OK;
+  if (b->d_meta) (void)hipFree(b->d_meta);
+  if (b->d_ints) (void)hipFree(b->d_ints);
+  delete b;
+  return SAGNN_OK;
+}
+
+extern "C" size_t sagnn_spmm_batch_workspace_bytes(const sagnn_spmm_batch* b, int d) {
+  if (!b || d <= 0) return 0;
+  return (size_t)b->n_chunks * (size_t)d * sizeof(float);
+}
+
+namespace {
+
+template <int LPR>
+int launch_batch(const sagnn_spmm_batch* b, int d, const DirArgs& au, const DirArgs& ai, float* partial, hipStream_t stream) {
+  constexpr int G = kWave / LPR;
+  constexpr int RPW_SMALL = G > 4 ? G : 4;
+  const bool small = (b->U > b->I ? b->U : b->I) < kSmallRows;
+  const int64_t rpb = (int64_t)kWavesPerBlock * (small ? RPW_SMALL : kRowsPerWave);
+  const int64_t chunk_blocks = (b->n_chunks + kWavesPerBlock - 1) / kWavesPerBlock;
+  const int64_t bu = (b->U + rpb - 1) / rpb, bi = (b->I + rpb - 1) / rpb;
+  const int64_t blocks = chunk_blocks + (int64_t)b->T * (bu + bi);
+  if (blocks > INT32_MAX || b->U > INT32_MAX || b->I > INT32_MAX) return sagnn::fail(SAGNN_ERR_ARG, "grid too large");
+  const BatchGeom g{b->T, (int32_t)chunk_blocks, (int32_t)bu, (int32_t)bi, (int32_t)b->U, (int32_t)b->I};
+  if (blocks > 0) {
+    sagnn::ProfileScope prof(sagnn::kProfSpmmRows, stream, b->nnz, (int64_t)b->T * (b->U + b->I));
+    if (small)
+      hipLaunchKernelGGL((spmm_rows_batch_kernel<LPR, RPW_SMALL>), dim3((unsigned)blocks), dim3(kBlock), 0, stream, b->d_meta,
+                         g, b->d_chunk_e0, b->d_chunk_e1, b->d_chunk_seg, b->n_chunks, partial, d, au, ai);
+    else
+      hipLaunchKernelGGL((spmm_rows_batch_kernel<LPR, kRowsPerWave>), dim3((unsigned)blocks), dim3(kBlock), 0, stream,
+                         b->d_meta, g, b->d_chunk_e0, b->d_chunk_e1, b->d_chunk_seg, b->n_chunks, partial, d, au, ai);
+    SAGNN_HIP_TRY(hipGetLastError());
+  }
+  if (b->n_long > 0) {
+    sagnn::ProfileScope prof(sagnn::kProfSpmmFixup, stream, b->n_chunks, b->n_long);
+    const int64_t fb = (b->n_long + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(spmm_fixup_batch_kernel<LPR>, dim3((unsigned)fb), dim3(kBlock), 0, stream, b->d_long_row,
+                       b->d_long_slot, b->d_long_seg, b->n_long, partial, d, b->T, au, ai);
+    SAGNN_HIP_TRY(hipGetLastError());
+  }
+  return SAGNN_OK;
+}
+
+int launch_batch_d(const sagnn_spmm_batch* b, int d, const DirArgs& au, const DirArgs& ai, float* partial, hipStream_t s) {
+  switch (sagnn::lanes_per_row(d)) {
+    case 8: return launch_batch<8>(b, d, au, ai, partial, s);
+    case 16: return launch_batch<16>(b, d, au, ai, partial, s);
+    case 32: return launch_batch<32>(b, d, au, ai, partial, s);
+    default: return launch_batch<64>(b, d, au, ai, partial, s);
+  }
+}
+
+struct Slab {           // a [T, N, d]-like operand: interval k's matrix starts at p + k * slab, rows ld apart
+  float* p;
+  int64_t ld, slab;
+};
+
+int check_slab(const char* name, const float* p, int64_t ld, int64_t slab, int d) {
+  if (int rc = check_mat(name, p, ld, d, true)) return rc;
+  if (slab & 3) return sagnn::fail(SAGNN_ERR_ALIGN, "%s: slab stride must be a multiple of 4", name);
+  return SAGNN_OK;
+}
+
+int check_batch_ws(const sagnn_spmm_batch* b, int d, const void* workspace, size_t workspace_bytes) {
+  const size_t need = sagnn_spmm_batch_workspace_bytes(b, d);
+  if (need == 0) return SAGNN_OK;
+  if (!workspace || workspace_bytes < need)
+    return sagnn::fail(SAGNN_ERR_WORKSPACE, "workspace needs %zu bytes, got %zu", need, workspace ? workspace_bytes : (size_t)0);
+  if (!sagnn::aligned16(workspace)) return sagnn::fail(SAGNN_ERR_ALIGN, "workspace not 16-byte aligned");
+  return SAGNN_OK;
+}
+
+}  // namespace
+
+// The whole GNN loop of model.py:118-129 — every interval, every layer — in L row launches (+ L fix-up launches when
+// the graphs have long rows): sagnn_gnn_interval_ex_f32 for all T intervals at once. Operands are slabs.
+extern "C" int sagnn_gnn_stack_f32(const sagnn_spmm_batch* b, const float* u0, int64_t ld_u0, int64_t slab_u0,
+                                   const float* i0, int64_t ld_i0, int64_t slab_i0, int d, int n_layers, float leaky,
+                                   float* scratch_u, float* scratch_i, float* user_out, int64_t ld_uo, int64_t slab_uo,
+                                   float* item_out, int64_t ld_io, int64_t slab_io, uint8_t* mask_u, uint8_t* mask_i,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!b) return sagnn::fail(SAGNN_ERR_NULL, "batch is NULL");
+  if (!u0 || !i0 || !user_out || !item_out) return sagnn::fail(SAGNN_ERR_NULL, "null embedding pointer");
+  if (d < 4 || d > 256 || (d & 3)) return sagnn::fail(SAGNN_ERR_DIM, "d = %d: need a multiple of 4 in [4, 256]", d);
+  if (n_layers < 1) return sagnn::fail(SAGNN_ERR_ARG, "n_layers = %d: need >= 1", n_layers);
+  if ((mask_u == nullptr) != (mask_i == nullptr)) return sagnn::fail(SAGNN_ERR_NULL, "give both masks or neither");
+  if (n_layers > 1 && (!scratch_u || !scratch_i)) return sagnn::fail(SAGNN_ERR_NULL, "scratch buffers required for n_layers > 1");
+  if (int rc = check_slab("u0", u0, ld_u0, slab_u0, d)) return rc;
+  if (int rc = check_slab("i0", i0, ld_i0, slab_i0, d)) return rc;
+  if (int rc = check_slab("user_out", user_out, ld_uo, slab_uo, d)) return rc;
+  if (int rc = check_slab("item_out", item_out, ld_io, slab_io, d)) return rc;
+  if (n_layers > 1 && (!sagnn::aligned16(scratch_u) || !sagnn::aligned16(scratch_i)))
+    return sagnn::fail(SAGNN_ERR_ALIGN, "scratch buffers must be 16-byte aligned");
+  if (int rc = check_batch_ws(b, d, workspace, workspace_bytes)) return rc;
+  const int64_t U = b->U, I = b->I, T = b->T;
+  const int64_t mrow = d / 4;
+  // e^l of interval k: layer 0 reads the callers' tables, layer l >= 1 the ping-pong scratch [2][T][N][d]
+  Slab cu{const_cast<float*>(u0), ld_u0, slab_u0}, ci{const_cast<float*>(i0), ld_i0, slab_i0};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  for (int l = 0; l < n_layers; ++l) {
+    const bool last = (l + 1 == n_layers);
+    DirArgs au{}, ai{};
+    au.ep.leaky = ai.ep.leaky = leaky;
+    au.ep.mask_stride = ai.ep.mask_stride = (int)mrow;
+    au.X = ci.p, au.ldx = ci.ld, au.s_X = ci.slab;       // rows = users gather item rows
+    ai.X = cu.p, ai.ldx = cu.ld, ai.s_X = cu.slab;
+    au.ep.residual = cu.p, au.ep.ldr = cu.ld, au.s_res = cu.slab;
+    ai.ep.residual = ci.p, ai.ep.ldr = ci.ld, ai.s_res = ci.slab;
+    Slab nu{nullptr, d, U * d}, ni{nullptr, d, I * d};
+    if (!last) {
+      nu.p = scratch_u + (int64_t)(l & 1) * T * U * d;
+      ni.p = scratch_i + (int64_t)(l & 1) * T * I * d;
+      au.ep.out = nu.p, au.ep.ldo = nu.ld, au.s_out = nu.slab;
+      ai.ep.out = ni.p, ai.ep.ldo = ni.ld, ai.s_out = ni.slab;
+    }
+    // running sum as in sagnn_gnn_interval_ex_f32: layer 0 of a deeper stack writes e^1 alone, layer 1 starts the sum
+    // from its residual, the last layer adds e^0 on the way out
+    if (last || l >= 1) {
+      if (l <= 1) {
+        au.ep.acc_in = cu.p, au.ep.ld_acc_in = cu.ld, au.s_acc_in = cu.slab;
+        ai.ep.acc_in = ci.p, ai.ep.ld_acc_in = ci.ld, ai.s_acc_in = ci.slab;
+      } else {
+        au.ep.acc_in = user_out, au.ep.ld_acc_in = ld_uo, au.s_acc_in = slab_uo;
+        ai.ep.acc_in = item_out, ai.ep.ld_acc_in = ld_io, ai.s_acc_in = slab_io;
+      }
+      au.ep.acc_out = user_out, au.ep.ld_acc_out = ld_uo, au.s_acc_out = slab_uo;
+      ai.ep.acc_out = item_out, ai.ep.ld_acc_out = ld_io, ai.s_acc_out = slab_io;
+      if (last && l >= 1) {
+        au.ep.acc_in2 = u0, au.ep.ld_acc_in2 = ld_u0, au.s_acc_in2 = slab_u0;
+        ai.ep.acc_in2 = i0, ai.ep.ld_acc_in2 = ld_i0, ai.s_acc_in2 = slab_i0;
+      }
+    }
+    if (mask_u) {   // [T][L][N][d/4]
+      au.ep.mask_out = mask_u + (int64_t)l * U * mrow, au.s_mask_out = (int64_t)n_layers * U * mrow;
+      ai.ep.mask_out = mask_i + (int64_t)l * I * mrow, ai.s_mask_out = (int64_t)n_layers * I * mrow;
+    }
+    if (int rc = launch_batch_d(b, d, au, ai, static_cast<float*>(workspace), s)) return rc;
+    cu = nu;
+    ci = ni;
+  }
+  return SAGNN_OK;
+}
+
+// Backward of sagnn_gnn_stack_f32 (see sagnn_gnn_interval_bwd_f32 for the recurrence): G_u / G_i are the gradients at the
+// interval outputs as slabs, masks [T][L][N][d/4] as the forward recorded them; scratch_x: [4][T][N][d]. `b` must be the
+// batch of the ADJOINT patterns (for canonical matrices: the same batch).
+extern "C" int sagnn_gnn_stack_bwd_f32(const sagnn_spmm_batch* b, const float* G_u, int64_t ld_gu, int64_t slab_gu,
+                                       const float* G_i, int64_t ld_gi, int64_t slab_gi, int d, int n_layers, float leaky,
+                                       const uint8_t* mask_u, const uint8_t* mask_i, float* scratch_u, float* scratch_i,
+                                       float* grad_u0, int64_t ld_du, int64_t slab_du, float* grad_i0, int64_t ld_di,
+                                       int64_t slab_di, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!b) return sagnn::fail(SAGNN_ERR_NULL, "batch is NULL");
+  if (!G_u || !G_i || !grad_u0 || !grad_i0 || !mask_u || !mask_i || !scratch_u || !scratch_i)
+    return sagnn::fail(SAGNN_ERR_NULL, "null pointer");
+  if (n_layers < 1) return sagnn::fail(SAGNN_ERR_ARG, "n_layers = %d: need >= 1", n_layers);
+  if (d < 4 || d > 256 || (d & 3)) return sagnn::fail(SAGNN_ERR_DIM, "d = %d: need a multiple of 4 in [4, 256]", d);
+  if (int rc = check_slab("G_u", G_u, ld_gu, slab_gu, d)) return rc;
+  if (int rc = check_slab("G_i", G_i, ld_gi, slab_gi, d)) return rc;
+  if (int rc = check_slab("grad_u0", grad_u0, ld_du, slab_du, d)) return rc;
+  if (int rc = check_slab("grad_i0", grad_i0, ld_di, slab_di, d)) return rc;
+  if (int rc = check_batch_ws(b, d, workspace, workspace_bytes)) return rc;
+  const int64_t U = b->U, I = b->I, T = b->T;
+  const int64_t mrow = d / 4;
+  const int64_t s_mask_u = (int64_t)n_layers * U * mrow, s_mask_i = (int64_t)n_layers * I * mrow;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* gfull_u[2] = {scratch_u, scratch_u + T * U * d};
+  float* gmask_u[2] = {scratch_u + 2 * T * U * d, scratch_u + 3 * T * U * d};
+  float* gfull_i[2] = {scratch_i, scratch_i + T * I * d};
+  float* gmask_i[2] = {scratch_i + 2 * T * I * d, scratch_i + 3 * T * I * d};
+  // seed: g^L * m^L of every interval (one launch per node type)
+  {
+    const int threads = 256;
+    const int64_t nu = U * mrow, ni = I * mrow;
+    if (nu > 0) {
+      hipLaunchKernelGGL(mask_scale_batch_kernel, dim3((unsigned)((nu + threads - 1) / threads), (unsigned)T), dim3(threads), 0, s,
+                         G_u, ld_gu, slab_gu, mask_u + (int64_t)(n_layers - 1) * U * mrow, s_mask_u, (int)mrow, leaky,
+                         gmask_u[0], (int64_t)d, U * d, U, d);
+      SAGNN_HIP_TRY(hipGetLastError());
+    }
+    if (ni > 0) {
+      hipLaunchKernelGGL(mask_scale_batch_kernel, dim3((unsigned)((ni + threads - 1) / threads), (unsigned)T), dim3(threads), 0, s,
+                         G_i, ld_gi, slab_gi, mask_i + (int64_t)(n_layers - 1) * I * mrow, s_mask_i, (int)mrow, leaky,
+                         gmask_i[0], (int64_t)d, I * d, I, d);
+      SAGNN_HIP_TRY(hipGetLastError());
+    }
+  }
+  Slab gun{const_cast<float*>(G_u), ld_gu, slab_gu}, gin{const_cast<float*>(G_i), ld_gi, slab_gi};   // g^{l+1}
+  int cur = 0;
+  for (int l = n_layers - 1; l >= 0; --l) {
+    const bool final_step = (l == 0);
+    DirArgs au{}, ai{};
+    au.ep.leaky = ai.ep.leaky = 1.f;
+    au.ep.mask_stride = ai.ep.mask_stride = (int)mrow;
+    au.X = gmask_i[cur], au.ldx = d, au.s_X = I * d;
+    ai.X = gmask_u[cur], ai.ldx = d, ai.s_X = U * d;
+    au.ep.residual = gun.p, au.ep.ldr = gun.ld, au.s_res = gun.slab;
+    ai.ep.residual = gin.p, ai.ep.ldr = gin.ld, ai.s_res = gin.slab;
+    au.ep.acc_in = G_u, au.ep.ld_acc_in = ld_gu, au.s_acc_in = slab_gu;
+    ai.ep.acc_in = G_i, ai.ep.ld_acc_in = ld_gi, ai.s_acc_in = slab_gi;
+    Slab ou = final_step ? Slab{grad_u0, ld_du, slab_du} : Slab{gfull_u[l & 1], d, U * d};
+    Slab oi = final_step ? Slab{grad_i0, ld_di, slab_di} : Slab{gfull_i[l & 1], d, I * d};
+    au.ep.acc_out = ou.p, au.ep.ld_acc_out = ou.ld, au.s_acc_out = ou.slab;
+    ai.ep.acc_out = oi.p, ai.ep.ld_acc_out = oi.ld, ai.s_acc_out = oi.slab;
+    if (!final_step) {
+      au.ep.mask_in = mask_u + (int64_t)(l - 1) * U * mrow, au.s_mask_in = s_mask_u;
+      ai.ep.mask_in = mask_i + (int64_t)(l - 1) * I * mrow, ai.s_mask_in = s_mask_i;
+      au.ep.out2 = gmask_u[cur ^ 1], au.ep.ldo2 = d, au.s_out2 = U * d;
+      ai.ep.out2 = gmask_i[cur ^ 1], ai.ep.ldo2 = d, ai.s_out2 = I * d;
+      au.ep.slope2 = ai.ep.slope2 = leaky;
+    }
+    if (int rc = launch_batch_d(b, d, au, ai, static_cast<float*>(workspace), s)) return rc;
+    gun = ou;
+    gin = oi;
     cur ^= 1;
   }
   return SAGNN_OK;

@@ -84,6 +84,19 @@ class Recommender:
         self.multihead_self_attention0 = MultiHeadSelfAttention(d, args.num_attention_heads)
         self.multihead_self_attention1 = MultiHeadSelfAttention(d, args.num_attention_heads)
 
+    # T-fold layer scratch and masks of the batched stack stay below this many bytes (dataset-sized graphs: Gowalla's
+    # scratch is 78 MB); above it every interval takes its own launches, which are long enough to hide their dispatch
+    BATCH_SCRATCH_LIMIT = 8 << 30
+
+    def _interval_batch(self):
+        """ops.SpmmBatch over the T interval plans, or None when the T-fold scratch would be too large."""
+        if self._batch is None and self._batch_ok is None:
+            T, d = args.graphNum, args.latdim
+            self._batch_ok = 2 * T * (args.user + args.item) * d * 4 <= self.BATCH_SCRATCH_LIMIT and T >= 1
+            if self._batch_ok:
+                self._batch = ops.SpmmBatch([a.plan for a in self.subAdj], [a.plan for a in self.subTpAdj])
+        return self._batch
+
     def propagate_intervals(self, intervals=None):
         """reference model.py:118-134: for every interval k the L-layer stack with residuals and
         add_n, written straight into [N, T, d] slabs (no stack/transpose pass). `intervals`
@@ -92,6 +105,17 @@ class Recommender:
         if self.user_vector_tensor is None:
             self.user_vector_tensor = torch.empty((args.user, T, d), dtype=torch.float32, device=self.device)
             self.item_vector_tensor = torch.empty((args.item, T, d), dtype=torch.float32, device=self.device)
+        batch = self._interval_batch() if (intervals is None and L > 0) else None
+        if batch is not None:
+            # every interval in one launch per layer (sagnn_gnn_stack_f32): the reference's loop over k is independent
+            # per interval, and on dataset-sized graphs its 2 T L SpMMs are bound by their launches
+            if L > 1 and (self._scratch_bu is None):
+                self._scratch_bu = torch.empty((2, T, args.user, d), dtype=torch.float32, device=self.device)
+                self._scratch_bi = torch.empty((2, T, args.item, d), dtype=torch.float32, device=self.device)
+            ops.gnn_stack(batch, self.uEmbed.detach(), self.iEmbed.detach(), L, NNs.leaky,
+                          self.user_vector_tensor.permute(1, 0, 2), self.item_vector_tensor.permute(1, 0, 2),
+                          self._scratch_bu, self._scratch_bi)
+            return self.user_vector_tensor, self.item_vector_tensor
         if L > 1 and self._scratch_u is None:
             self._scratch_u = torch.empty((2, args.user, d), dtype=torch.float32, device=self.device)
             self._scratch_i = torch.empty((2, args.item, d), dtype=torch.float32, device=self.device)
@@ -334,7 +358,11 @@ class Recommender:
         T, L, d, heads, leaky = args.graphNum, args.gnn_layer, args.latdim, args.num_attention_heads, NNs.leaky
         keep = args.keepRate if keep_rate is None else keep_rate
         # one autograd node for the whole interval loop; uv / iv are [T, N, d] slabs written in place
-        uv, iv = ag.gnn_stack(self.uEmbed, self.iEmbed, [a.plan for a in self.subAdj], [a.plan for a in self.subTpAdj], L, leaky)
+        batch_ = self._interval_batch()
+        if batch_ is not None:
+            uv, iv = ag.gnn_stack(self.uEmbed, self.iEmbed, batch_, None, L, leaky)
+        else:
+            uv, iv = ag.gnn_stack(self.uEmbed, self.iEmbed, [a.plan for a in self.subAdj], [a.plan for a in self.subTpAdj], L, leaky)
         finals = []
         for xs, (gamma, beta), att, key in ((uv, self.ln[0], self.multihead_self_attention0, "drop_u"),
                                             (iv, self.ln[1], self.multihead_self_attention1, "drop_i")):
@@ -587,7 +615,8 @@ class Recommender:
             self.subTpAdj.append(tp)
         self.maxTime = self.handler.maxTime
         self.user_vector_tensor = self.item_vector_tensor = None
-        self._scratch_u = self._scratch_i = None
+        self._scratch_u = self._scratch_i = self._scratch_bu = self._scratch_bi = None
+        self._batch, self._batch_ok = None, None
         self.final_user_vector, self.final_item_vector = self.ours()
 
     def makePrint(self, name, ep, reses, save):

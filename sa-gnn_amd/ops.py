@@ -262,6 +262,132 @@ def gnn_interval_bwd(plan_user: SpmmPlan, plan_item: SpmmPlan, grad_user_out: to
     return grad_u0, grad_i0
 
 
+class SpmmBatch:
+    """The T interval plans of a model tied into one launch per layer (sagnn_spmm_batch_*): what the reference's
+    `for k in range(args.graphNum)` loop (model.py:118) becomes when its 2 T L SpMMs are launch-bound. Keeps the
+    plans alive. `adjoint()` is the batch the backward pass runs on (the same one unless a matrix holds duplicated
+    stored entries, graph.interval_pair)."""
+
+    def __init__(self, plans_user, plans_item):
+        if len(plans_user) != len(plans_item) or not plans_user:
+            raise ValueError("one user-side and one item-side plan per interval")
+        self.plans_user, self.plans_item = list(plans_user), list(plans_item)
+        self.T, self.U, self.I = len(plans_user), plans_user[0].n_rows, plans_item[0].n_rows
+        self.device = plans_user[0].device
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        PU = (ctypes.c_void_p * self.T)(*[p.handle for p in self.plans_user])
+        PI = (ctypes.c_void_p * self.T)(*[p.handle for p in self.plans_item])
+        check(self._lib.sagnn_spmm_batch_create(PU, PI, self.T, ctypes.byref(self._h)))
+        self.nnz = sum(p.nnz for p in self.plans_user) + sum(p.nnz for p in self.plans_item)
+        self._ws: dict[int, torch.Tensor] = {}
+        self._adjoint: SpmmBatch | None = None
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self._lib.sagnn_spmm_batch_destroy(h)
+            self._h = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def workspace(self, d: int):
+        need = int(self._lib.sagnn_spmm_batch_workspace_bytes(self._h, int(d)))
+        if need == 0:
+            return None
+        ws = self._ws.get(d)
+        if ws is None:
+            ws = torch.empty(need // 4, dtype=torch.float32, device=self.device)
+            self._ws[d] = ws
+        return ws
+
+    def adjoint(self) -> "SpmmBatch":
+        adj_u = [p.partner_adjoint for p in self.plans_user]
+        adj_i = [p.partner_adjoint for p in self.plans_item]
+        if all(a is None for a in adj_u + adj_i):
+            for pu, pi in zip(self.plans_user, self.plans_item):
+                if pu.nnz != pi.nnz:
+                    raise ValueError("plans are not a transposed pair (duplicated stored entries?) — build them with "
+                                     "graph.interval_pair, which adds the exact adjoints")
+            return self
+        if self._adjoint is None:
+            self._adjoint = SpmmBatch([a if a is not None else p for a, p in zip(adj_u, self.plans_user)],
+                                      [a if a is not None else p for a, p in zip(adj_i, self.plans_item)])
+        return self._adjoint
+
+
+def _slab(name: str, x: torch.Tensor, T: int, rows: int, d: int):
+    """x indexed [interval, row, feature] with unit feature stride (any other strides: [T, N, d] storage or a
+    permuted view of [N, T, d]); returns (ld, slab) in elements."""
+    if x.dtype != torch.float32 or not x.is_cuda or x.dim() != 3 or tuple(x.shape) != (T, rows, d) or x.stride(2) != 1:
+        raise ValueError(f"{name}: expected a float32 device tensor indexed [{T}, {rows}, {d}] with unit feature stride, "
+                         f"got {tuple(x.shape)} strides {x.stride()}")
+    ld = int(x.stride(1)) if rows > 1 else max(int(x.stride(1)), d)
+    slab = int(x.stride(0)) if T > 1 else 0
+    return ld, slab
+
+
+def gnn_stack(batch: SpmmBatch, u0: torch.Tensor, i0: torch.Tensor, n_layers: int, leaky: float,
+              user_out: torch.Tensor, item_out: torch.Tensor, scratch_u: torch.Tensor | None = None,
+              scratch_i: torch.Tensor | None = None, mask_u: torch.Tensor | None = None, mask_i: torch.Tensor | None = None):
+    """Every interval of the GNN loop (reference model.py:118-129) in one launch per layer: sagnn_gnn_stack_f32.
+    u0 [T, U, d], i0 [T, I, d]; user_out / item_out indexed [T, N, d] (e.g. `x.permute(1, 0, 2)` of the [N, T, d]
+    tensor the fusion reads); mask_u [T, L, U, d/4] / mask_i [T, L, I, d/4] uint8 for training."""
+    T, U, I = batch.T, batch.U, batch.I
+    d = int(u0.shape[2])
+    ld_u0, sl_u0 = _slab("u0", u0, T, U, d)
+    ld_i0, sl_i0 = _slab("i0", i0, T, I, d)
+    ld_uo, sl_uo = _slab("user_out", user_out, T, U, d)
+    ld_io, sl_io = _slab("item_out", item_out, T, I, d)
+    if n_layers > 1:
+        if scratch_u is None:
+            scratch_u = torch.empty((2, T, U, d), dtype=torch.float32, device=u0.device)
+        if scratch_i is None:
+            scratch_i = torch.empty((2, T, I, d), dtype=torch.float32, device=u0.device)
+        for name, s_, rows in (("scratch_u", scratch_u, U), ("scratch_i", scratch_i, I)):
+            if s_.dtype != torch.float32 or not s_.is_contiguous() or s_.numel() < 2 * T * rows * d:
+                raise ValueError(f"{name}: need a contiguous float32 buffer of 2*{T}*{rows}*{d} elements")
+    for name, m, rows in (("mask_u", mask_u, U), ("mask_i", mask_i, I)):
+        if m is not None and (m.dtype != torch.uint8 or not m.is_contiguous() or m.numel() != T * n_layers * rows * (d // 4)):
+            raise ValueError(f"{name}: need a contiguous uint8 tensor [{T}, {n_layers}, {rows}, {d // 4}]")
+    ws = batch.workspace(d)
+    check(batch._lib.sagnn_gnn_stack_f32(batch.handle, _ptr(u0), ld_u0, sl_u0, _ptr(i0), ld_i0, sl_i0, d, int(n_layers),
+                                         float(leaky), _ptr(scratch_u), _ptr(scratch_i), _ptr(user_out), ld_uo, sl_uo,
+                                         _ptr(item_out), ld_io, sl_io, _ptr(mask_u), _ptr(mask_i), _ptr(ws),
+                                         0 if ws is None else ws.numel() * 4, _stream()))
+    return user_out, item_out
+
+
+def gnn_stack_bwd(batch: SpmmBatch, grad_user_out: torch.Tensor, grad_item_out: torch.Tensor, n_layers: int, leaky: float,
+                  mask_u: torch.Tensor, mask_i: torch.Tensor, grad_u0: torch.Tensor, grad_i0: torch.Tensor,
+                  scratch_u: torch.Tensor | None = None, scratch_i: torch.Tensor | None = None):
+    """Backward of gnn_stack (sagnn_gnn_stack_bwd_f32) on the batch's adjoint patterns: gradients at the interval
+    outputs [T, N, d] (any strides) -> dL/d u0 [T, U, d], dL/d i0 [T, I, d]."""
+    adj = batch.adjoint()
+    T, U, I = batch.T, batch.U, batch.I
+    d = int(grad_user_out.shape[2])
+    ld_gu, sl_gu = _slab("grad_user_out", grad_user_out, T, U, d)
+    ld_gi, sl_gi = _slab("grad_item_out", grad_item_out, T, I, d)
+    ld_du, sl_du = _slab("grad_u0", grad_u0, T, U, d)
+    ld_di, sl_di = _slab("grad_i0", grad_i0, T, I, d)
+    dev = grad_user_out.device
+    if scratch_u is None:
+        scratch_u = torch.empty((4, T, U, d), dtype=torch.float32, device=dev)
+    if scratch_i is None:
+        scratch_i = torch.empty((4, T, I, d), dtype=torch.float32, device=dev)
+    for name, m, rows in (("mask_u", mask_u, U), ("mask_i", mask_i, I)):
+        if m.dtype != torch.uint8 or not m.is_contiguous() or m.numel() != T * n_layers * rows * (d // 4):
+            raise ValueError(f"{name}: need a contiguous uint8 tensor [{T}, {n_layers}, {rows}, {d // 4}]")
+    ws = adj.workspace(d)
+    check(adj._lib.sagnn_gnn_stack_bwd_f32(adj.handle, _ptr(grad_user_out), ld_gu, sl_gu, _ptr(grad_item_out), ld_gi, sl_gi, d,
+                                           int(n_layers), float(leaky), _ptr(mask_u), _ptr(mask_i), _ptr(scratch_u),
+                                           _ptr(scratch_i), _ptr(grad_u0), ld_du, sl_du, _ptr(grad_i0), ld_di, sl_di, _ptr(ws),
+                                           0 if ws is None else ws.numel() * 4, _stream()))
+    return grad_u0, grad_i0
+
+
 def _ntd(name: str, x: torch.Tensor, dense_td: bool = False):
     """x is indexed [node, interval, feature]; any node/interval strides (so a permuted view of
     [t, n, d] storage works). Returns n, t, d, ld_n, ld_t."""

@@ -199,3 +199,96 @@ def test_spmm_powerlaw_properties_large(dev):
     # leaky applies to the sum, not per edge: negative sums scale by the slope
     s = ops.spmm(pu, x1, 1.0)
     torch.testing.assert_close(ops.spmm(pu, x1, 0.5), torch.maximum(0.5 * s, s))
+
+
+def _intervals(rng, U, I, T, dens):
+    mats = []
+    for k in range(T):
+        m = (rng.random((U, I)) < dens[k % len(dens)]).astype(np.intc)
+        m[3, :] = 1                       # a user with every item: a long row of the user side
+        m[:, 5] = 1                       # an item with every user: a long row of the item side
+        if k == 1:
+            m[10:40, :] = 0               # isolated users in this interval only
+        mats.append(sp.csr_matrix(m))
+    return mats
+
+
+@pytest.mark.parametrize("d,L,T", [(64, 2, 3), (32, 1, 5), (128, 3, 4), (64, 3, 5)])
+def test_gnn_stack_one_launch_per_layer_vs_oracle(dev, d, L, T):
+    """sagnn_gnn_stack_f32: every interval of the loop of model.py:118-129 in ONE launch per layer (+ one fix-up
+    launch), all three degree classes in every interval (tuning 8 / 24 / 64), outputs written as columns of the
+    [N, T, d] tensors the fusion reads. Against O.gnn_stack, and bit for bit against the per-interval entry
+    (same kernel bodies, same order of additions)."""
+    from sa_gnn_amd import graph, ops
+    rng = np.random.default_rng(7 * d + L + T)
+    U, I = 301, 211
+    mats = _intervals(rng, U, I, T, (0.04, 0.09, 0.02))
+    pairs = [graph.interval_pair(m, dev, tuning=(8, 24, 64)) for m in mats]
+    ue = rng.standard_normal((T, U, d)).astype(np.float32)
+    ie = rng.standard_normal((T, I, d)).astype(np.float32)
+    batch = ops.SpmmBatch([p[0].plan for p in pairs], [p[1].plan for p in pairs])
+    assert all(p[0].plan.info.n_long_rows > 0 and p[1].plan.info.n_long_rows > 0 for p in pairs)
+    ued, ied = torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev)
+    us = torch.full((U, T, d), 7.0, device=dev)
+    its = torch.full((I, T, d), 7.0, device=dev)
+    lib = ops._lib.load()
+    lib.sagnn_profile_enable(64)
+    ops.gnn_stack(batch, ued, ied, L, 0.5, us.permute(1, 0, 2), its.permute(1, 0, 2))
+    import ctypes
+    n, kinds = ctypes.c_int(0), (ctypes.c_int32 * 64)()
+    ops.check(lib.sagnn_profile_read(None, kinds, None, None, 64, ctypes.byref(n)))
+    lib.sagnn_profile_enable(0)
+    assert [kinds[i] for i in range(n.value)] == [0, 1] * L              # one row launch + one fix-up per layer
+    adjs = [O.trans_to_lsts(m)[0] for m in mats]
+    tps = [O.trans_to_lsts(O.transpose(m))[0] for m in mats]
+    want_u, want_i = O.gnn_stack(ue, ie, adjs, tps, L, 0.5)              # [U, T, d], [I, T, d]
+    terms_u, terms_i = O.gnn_stack(np.abs(ue), np.abs(ie), adjs, tps, L, 1.0)
+    assert_sum_close(us.cpu().numpy(), want_u, terms_u)
+    assert_sum_close(its.cpu().numpy(), want_i, terms_i)
+    us2 = torch.empty((U, T, d), device=dev)
+    its2 = torch.empty((I, T, d), device=dev)
+    for k in range(T):
+        ops.gnn_interval(pairs[k][0].plan, pairs[k][1].plan, ued[k], ied[k], L, 0.5, us2[:, k, :], its2[:, k, :])
+    assert torch.equal(us, us2) and torch.equal(its, its2)
+    # [T, N, d] storage as well (the training path's slabs), and the recorded masks
+    out_u, out_i = torch.empty((T, U, d), device=dev), torch.empty((T, I, d), device=dev)
+    mu = torch.zeros((T, L, U, d // 4), dtype=torch.uint8, device=dev)
+    mi = torch.zeros((T, L, I, d // 4), dtype=torch.uint8, device=dev)
+    ops.gnn_stack(batch, ued, ied, L, 0.5, out_u, out_i, mask_u=mu, mask_i=mi)
+    assert torch.equal(out_u.permute(1, 0, 2), us) and torch.equal(out_i.permute(1, 0, 2), its)
+    mu2 = torch.zeros((L, U, d // 4), dtype=torch.uint8, device=dev)
+    mi2 = torch.zeros((L, I, d // 4), dtype=torch.uint8, device=dev)
+    for k in range(T):
+        ops.gnn_interval(pairs[k][0].plan, pairs[k][1].plan, ued[k], ied[k], L, 0.5, us2[:, k, :], its2[:, k, :], mask_u=mu2, mask_i=mi2)
+        assert torch.equal(mu[k], mu2) and torch.equal(mi[k], mi2)
+
+
+@pytest.mark.parametrize("d,L,T", [(64, 2, 3), (32, 3, 4)])
+def test_gnn_stack_backward_matches_per_interval_backward(dev, d, L, T):
+    """sagnn_gnn_stack_bwd_f32 against sagnn_gnn_interval_bwd_f32 interval by interval (itself checked against
+    float64 autograd in tests/test_gpu_backward.py), through the autograd node with a duplicated stored entry in one
+    interval (exact adjoint plans)."""
+    from sa_gnn_amd import autograd as ag
+    from sa_gnn_amd import graph, ops
+    rng = np.random.default_rng(11 * d + L)
+    U, I = 157, 263
+    mats = _intervals(rng, U, I, T, (0.05, 0.03))
+    m = mats[0]
+    indptr, indices = m.indptr.copy(), m.indices.copy()
+    indices[indptr[7] + 1] = indices[indptr[7]]                          # row 7 stores one (u, i) twice
+    mats[0] = sp.csr_matrix((np.ones(len(indices), np.intc), indices, indptr), shape=(U, I))
+    pairs = [graph.interval_pair(mm, dev, tuning=(8, 24, 64)) for mm in mats]
+    assert pairs[0][0].plan.partner_adjoint is not None
+    batch = ops.SpmmBatch([p[0].plan for p in pairs], [p[1].plan for p in pairs])
+    ue = torch.from_numpy(rng.standard_normal((T, U, d)).astype(np.float32)).to(dev)
+    ie = torch.from_numpy(rng.standard_normal((T, I, d)).astype(np.float32)).to(dev)
+    gu = torch.from_numpy(rng.standard_normal((U, T, d)).astype(np.float32)).to(dev)       # gradients arrive as [N, T, d] views
+    gi = torch.from_numpy(rng.standard_normal((I, T, d)).astype(np.float32)).to(dev)
+    res = []
+    for plans in ((batch, None), ([p[0].plan for p in pairs], [p[1].plan for p in pairs])):
+        a, b = ue.clone().requires_grad_(True), ie.clone().requires_grad_(True)
+        ou, oi = ag.gnn_stack(a, b, plans[0], plans[1], L, 0.5)
+        ((ou.permute(1, 0, 2) * gu).sum() + (oi.permute(1, 0, 2) * gi).sum()).backward()
+        res.append((ou.detach(), oi.detach(), a.grad, b.grad))
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
