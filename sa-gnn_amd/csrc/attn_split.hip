@@ -81,6 +81,24 @@ struct HeadVec<8> {
   }
 };
 
+// Sum over the LPR lanes that hold one row (8, 16 or 32 consecutive lanes), result in every lane: DPP butterflies
+// inside the 16-lane row (one VALU instruction each), a ds_bpermute only for the step across two rows (d = 128).
+// The ds_bpermute form of every step was a chain of 8 dependent LDS round trips per row and pass — a tenth of the
+// kernel's time at d = 64, a sixth at d = 128.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+  v = dpp_add<0xB1>(v);                            // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);                            // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);                           // row_half_mirror
+  if constexpr (LPR >= 16) v = dpp_add<0x140>(v);  // row_mirror
+  if constexpr (LPR == 32) v += __shfl_xor(v, 16);
+  return v;
+}
+
 // T: intervals (compile time). LP = lanes_per_pair(T, D). d = 128: a workgroup (4 waves) covers 64 of the 128
 // output columns of each of Q, K, V; blockIdx.y picks the half (the layer norm is evaluated by both).
 // BWD (front of the attention backward pass, LP = 1): `out` is the UPSTREAM gradient dL/d(mean context) [n, d] (read),
@@ -189,14 +207,9 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
     if (apply_ln) {
 #pragma unroll
       for (int p = 0; p < NFILL; ++p) {
-        float s = (xr[p].x + xr[p].y) + (xr[p].z + xr[p].w);
-#pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o);
-        const float mr = s * (1.f / (float)D);
+        const float mr = row_sum<LPR>((xr[p].x + xr[p].y) + (xr[p].z + xr[p].w)) * (1.f / (float)D);
         const float dx = xr[p].x - mr, dy = xr[p].y - mr, dz = xr[p].z - mr, dw = xr[p].w - mr;
-        float m2 = (dx * dx + dy * dy) + (dz * dz + dw * dw);
-#pragma unroll
-        for (int o = 1; o < LPR; o <<= 1) m2 += __shfl_xor(m2, o);
+        const float m2 = row_sum<LPR>((dx * dx + dy * dy) + (dz * dz + dw * dw));
         if (fc4_ == 0) rstat[p * RPP + fr_] = make_float2(mr, m2);
       }
       lds_barrier();
