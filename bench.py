@@ -71,6 +71,8 @@ def parse():
                         "path (loss = sum of the fused embeddings; N > 1: reverse all-to-all + reduce-scatter) — "
                         "not the headline metric")
     p.add_argument("--exchange", default="alltoall", choices=["alltoall", "allgather"])
+    p.add_argument("--split", default="fractional", choices=["fractional", "groups"],
+                   help="T < world: edge-balanced fractional row cuts across all ranks (default) or whole-rank groups per interval")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-breakdown", action="store_true",
                    help="N > 1: skip the extra untimed-for-the-metric passes (SpMM only / exchange only / fusion only)")
@@ -131,9 +133,9 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     import torch.distributed as dist
     from sa_gnn_amd import _lib, ops, synthetic
-    from sa_gnn_amd.parallel import (ChunkedGather, RoundFusion, RowShardExchange, SplitIntervalRunner,
-                                     SplitIntervalSharding, csr_row_slice, exchange_to_row_shards, gather_fused,
-                                     make_sharding)
+    from sa_gnn_amd.parallel import (ChunkedGather, FractionalRunner, FractionalSharding, RoundFusion, RowShardExchange,
+                                     SplitIntervalRunner, SplitIntervalSharding, csr_row_slice, exchange_to_row_shards,
+                                     gather_fused, make_sharding)
 
     rehearsal = world > 1 and a.dist_backend == "gloo"
     if rehearsal:
@@ -159,17 +161,20 @@ def main():
     d, L, heads = w["d"], w["layers"], 16
     T = w["t_per_gpu"] * world if scaling == "weak" else w["t_total"]
     nnz_of = (lambda k: int(w["nnz"][k] * a.scale)) if isinstance(w["nnz"], list) else (lambda k: int(w["nnz"] * a.scale))
-    sh = make_sharding(T, world, rank, weights=[nnz_of(k) for k in range(T)])
-    split = isinstance(sh, SplitIntervalSharding)       # T < world: rank groups split an interval's target rows
+    sh = make_sharding(T, world, rank, weights=[nnz_of(k) for k in range(T)], split=a.split)
+    frac = isinstance(sh, FractionalSharding)           # T < world: edge-balanced stretches of the concatenated intervals
+    split = isinstance(sh, SplitIntervalSharding) or frac     # T < world: ranks split an interval's target rows
     if split and a.exchange != "alltoall":
         raise SystemExit("T < world runs the all-to-all exchange only")
     if split and a.stages == "train":
-        raise SystemExit("--stages train needs whole intervals per rank (T >= world)")
+        raise SystemExit("--stages train with T < world: the backward of the row-split stack is not built (it needs the adjoint "
+                         "of every member's row-slice SpMM — a column-sliced transposed plan per member — and a reduce-scatter "
+                         "of the partial source gradients inside each interval's group per layer); T >= world trains")
     tuning = tuple(int(v) for v in a.tuning.split(",")) if a.tuning else None
     group = None
     if split:
         groups = [dist.new_group(sh.members(k)) for k in range(T)]     # every rank creates every group, same order
-        group = groups[sh.interval]
+        group = None if frac else groups[sh.interval]
 
     # ---- build the rank's interval graphs and parameters (untimed) --------------------------
     t0 = time.time()
@@ -180,7 +185,7 @@ def main():
         (rp_u, ci_u), (rp_i, ci_i) = synthetic.csr_pair_from_edges(u, i, U, I)
         del u, i
         if split:                                        # this member's target-row slices, full source tables
-            (lu, hu), (li, hi) = sh.slice_range(U), sh.slice_range(I)
+            (lu, hu), (li, hi) = (sh.slice_range(U, k), sh.slice_range(I, k)) if frac else (sh.slice_range(U), sh.slice_range(I))
             rp_u, ci_u = csr_row_slice(rp_u, ci_u, lu, hu)
             rp_i, ci_i = csr_row_slice(rp_i, ci_i, li, hi)
             pu = ops.SpmmPlan(rp_u.contiguous(), ci_u.contiguous(), hu - lu, I, device=dev, tuning=tuning, validate=False)
@@ -216,7 +221,12 @@ def main():
     t_loc = len(sh.local_intervals)
     overlap = world > 1 and a.exchange == "alltoall"
     comm_dev = torch.device("cpu") if rehearsal else dev          # gloo rehearsal: collectives on host copies
-    runner = SplitIntervalRunner(sh, U, I, d, dev, group=group, comm_device=comm_dev) if split else None
+    if frac:
+        runner = FractionalRunner(sh, U, I, d, dev, {k: groups[k] for k in sh.local_intervals}, comm_device=comm_dev)
+        frac_plans = {k: plans[j] for j, k in enumerate(sh.local_intervals)}
+        frac_emb = {k: emb[j] for j, k in enumerate(sh.local_intervals)}
+    else:
+        runner = SplitIntervalRunner(sh, U, I, d, dev, group=group, comm_device=comm_dev) if split else None
     if not split:
         out_u = torch.empty((max(t_loc, 1), U, d), device=dev)[:t_loc]
         out_i = torch.empty((max(t_loc, 1), I, d), device=dev)[:t_loc]
@@ -236,7 +246,10 @@ def main():
 
     def spmm_stack(post: bool):
         if split:
-            acc_u, acc_i = runner.run(ops.spmm, plans[0][0], plans[0][1], emb[0][0], emb[0][1], L, 0.5)
+            if frac:
+                acc_u, acc_i = runner.run(ops.spmm, frac_plans, frac_emb, L, 0.5)
+            else:
+                acc_u, acc_i = runner.run(ops.spmm, plans[0][0], plans[0][1], emb[0][0], emb[0][1], L, 0.5)
             if post:
                 ex_u.post(acc_u.to(comm_dev))
                 ex_i.post(acc_i.to(comm_dev))
@@ -483,7 +496,10 @@ def main():
                                             "the SpMM itself is plain fp32)",
                                    "f32": "f32 MFMA (v_mfma_f32_32x32x2_f32: an fp32 fmaf chain)",
                                    "valu": "VALU fp32"}[ops.get_engine()],
-                   "partitioning": (f"T < world: {sh.group_size} ranks per interval, target rows split inside a group; fusion row-sharded"
+                   "partitioning": ("T < world: rank r computes the stretch [r, r + 1) / world of the intervals' target rows laid end "
+                                    f"to end by edge count (intervals met by each rank: {[sh.intervals_of(r) for r in range(world)]}); fusion row-sharded"
+                                    if frac else
+                                    f"T < world: {sh.group_size} ranks per interval, target rows split inside a group; fusion row-sharded"
                                     if split else f"interval k -> rank k mod {world}; fusion row-sharded")},
         "ms_per_step_rank0": {"median": float(np.median(step_ms)), "min": float(np.min(step_ms)), "max": float(np.max(step_ms)),
                               "note": "device time between step marks on the launch stream; ms_per_step is wall / steps"},
@@ -536,8 +552,8 @@ def main():
             if overlap:
                 def exchange_only():
                     if split:
-                        ex_u.post(runner.acc_u.to(comm_dev))
-                        ex_i.post(runner.acc_i.to(comm_dev))
+                        ex_u.post((runner.out_u if frac else runner.acc_u).to(comm_dev))
+                        ex_i.post((runner.out_i if frac else runner.acc_i).to(comm_dev))
                     else:
                         for j in range(t_loc):
                             ex_u.post(out_u[j].to(comm_dev))

@@ -22,6 +22,13 @@ members of a group split the TARGET ROWS of their interval (`SplitIntervalShardi
 the members all-gather the layer output inside the group before the next layer reads it, and the
 slice of the running sum goes straight into the same all-to-all (sender order = interval order, so
 x [T, rows_r, d] is still received in place). Steps 3 and 4 are unchanged.
+
+Whole-rank groups balance badly when the ranks do not divide by the intervals (Amazon's T = 5 on 8 ranks:
+groups [1, 2, 2, 2, 1], busiest rank 72 k edges against 44 k ideal), so the default for T < world is
+`FractionalSharding`: the intervals' target rows are laid end to end on one axis weighted by the intervals' edge
+counts, and rank r takes the stretch [r, r + 1) / world of it — the tail rows of one interval and the head rows of
+the next where the cut falls inside an interval (`FractionalRunner`). Every rank then carries E / world edges (rows
+of an interval are taken as equally heavy: user ids and the generator's item permutation are random).
 """
 from __future__ import annotations
 
@@ -123,11 +130,182 @@ class SplitIntervalSharding(IntervalSharding):
         return ins, outs
 
 
-def make_sharding(n_intervals: int, world: int, rank: int, weights=None) -> IntervalSharding:
-    """Cyclic interval sharding when every rank gets an interval, group/row-split sharding otherwise."""
+class FractionalSharding(IntervalSharding):
+    """T < world with edge-balanced cuts: the T intervals lie end to end on [0, 1) in proportion to `weights`
+    (edges per interval); rank r owns [r / world, (r + 1) / world). Its SEGMENTS are the intervals that stretch
+    meets, each with the fraction range (f0, f1) of the interval's target rows it computes — the same fractions for
+    the user side and the item side. The ranks that meet interval k are consecutive (`members(k)`), a rank may sit in
+    two neighbouring groups. Exact rational arithmetic on integer weights: every rank derives the same cuts."""
+
+    def __init__(self, n_intervals: int, world: int, rank: int, weights=None):
+        super().__init__(n_intervals, world, rank)
+        if not (1 <= self.T < self.world):
+            raise ValueError(f"fractional sharding is for 1 <= T < world, got T={n_intervals}, world={world}")
+        w = [1] * self.T if weights is None else [int(v) for v in weights]
+        if len(w) != self.T or min(w) < 0:
+            raise ValueError("weights: one non-negative integer per interval")
+        if sum(w) == 0:
+            w = [1] * self.T
+        self.w, self.W = w, sum(w)
+        self.cum = [0]
+        for v in w:
+            self.cum.append(self.cum[-1] + v)
+        self.rounds = 1
+        self._segs = [self._segments_of(r) for r in range(self.world)]
+
+    def _segments_of(self, r: int):
+        # everything in units of 1 / (W * world): rank r = [r W, (r + 1) W), interval k = [cum_k world, cum_{k+1} world)
+        lo, hi = r * self.W, (r + 1) * self.W
+        segs = []
+        for k in range(self.T):
+            a, b = self.cum[k] * self.world, self.cum[k + 1] * self.world
+            x0, x1 = max(lo, a), min(hi, b)
+            if x1 > x0 and b > a:
+                segs.append((k, (x0 - a, b - a), (x1 - a, b - a)))       # fractions as (numerator, denominator)
+        return segs
+
+    def segments(self, r: int | None = None):
+        """[(interval, member index in its group)] of rank r, ascending in the interval."""
+        r = self.rank if r is None else r
+        return [(k, r - self.members(k)[0]) for k, _, _ in self._segs[r]]
+
+    def members(self, k: int):
+        return [r for r in range(self.world) if any(s[0] == k for s in self._segs[r])]
+
+    def intervals_of(self, r: int):
+        return [s[0] for s in self._segs[r]]
+
+    def owner(self, k: int) -> int:
+        return self.members(k)[0]
+
+    def cuts(self, n_rows: int, k: int):
+        """g + 1 row offsets of interval k's member slices ([0 .. n_rows], monotone)."""
+        mem = self.members(k)
+        b = [0]
+        for r in mem:
+            (_, _, (num, den)) = next(s for s in self._segs[r] if s[0] == k)
+            b.append((num * int(n_rows)) // den)
+        b[-1] = int(n_rows)
+        return b
+
+    def slice_range(self, n_rows: int, k: int, r: int | None = None):
+        r = self.rank if r is None else r
+        mem = self.members(k)
+        c = self.cuts(n_rows, k)
+        m = mem.index(r)
+        return c[m], c[m + 1]
+
+    def exchange_splits(self, n_rows: int):
+        """(ins, outs) of the ONE all-to-all in rows: what this rank's segments (in interval order) send to each row
+        shard, what it receives from each sender (whose block is ordered (interval, row), which is the order of
+        x [T, rows_local, d] because ranks are monotone in the interval)."""
+        b = self.row_bounds(n_rows)
+        ov = lambda a0, a1, b0, b1: max(0, min(a1, b1) - max(a0, b0))     # noqa: E731
+        ins = [sum(ov(*self.slice_range(n_rows, k), b[r], b[r + 1]) for k in self.intervals_of(self.rank)) for r in range(self.world)]
+        mine = (b[self.rank], b[self.rank + 1])
+        outs = [sum(ov(*self.slice_range(n_rows, k, s), *mine) for k in self.intervals_of(s)) for s in range(self.world)]
+        return ins, outs
+
+    def send_order(self, n_rows: int):
+        """Row pieces of this rank's concatenated segment rows in SEND order (destination shard, then interval):
+        [(offset, length)] into the concatenation; all_to_all_single wants the input grouped by destination."""
+        b = self.row_bounds(n_rows)
+        base, segs = 0, []
+        for k in self.intervals_of(self.rank):
+            lo, hi = self.slice_range(n_rows, k)
+            segs.append((base, lo, hi))
+            base += hi - lo
+        pieces = []
+        for r in range(self.world):
+            for off, lo, hi in segs:
+                a0, a1 = max(lo, b[r]), min(hi, b[r + 1])
+                if a1 > a0:
+                    pieces.append((off + a0 - lo, a1 - a0))
+        return pieces
+
+
+def make_sharding(n_intervals: int, world: int, rank: int, weights=None, split: str = "fractional") -> IntervalSharding:
+    """Cyclic interval sharding when every rank gets an interval; for T < world the edge-balanced fractional cuts
+    (split="fractional", the default) or whole-rank groups (split="groups")."""
     if 1 <= n_intervals < world:
-        return SplitIntervalSharding(n_intervals, world, rank, weights)
+        if split == "groups":
+            return SplitIntervalSharding(n_intervals, world, rank, weights)
+        return FractionalSharding(n_intervals, world, rank, None if weights is None else [int(v) for v in weights])
     return IntervalSharding(n_intervals, world, rank)
+
+
+def _all_gather_rows(table: torch.Tensor, cuts, m: int, group, comm_device=None):
+    """table [N, d] with this member's rows [cuts[m], cuts[m+1]) up to date -> every member's rows. Slices differ in
+    length: RCCL takes the uneven list form directly (grouped broadcasts); gloo needs equal pieces, so the gloo
+    path pads to the longest slice."""
+    g = len(cuts) - 1
+    if g == 1:
+        return
+    staged = comm_device is not None and torch.device(comm_device) != table.device
+    if dist.get_backend(group) != "gloo" and not staged:
+        outs = [table[cuts[j]:cuts[j + 1]] for j in range(g)]
+        dist.all_gather(outs, table[cuts[m]:cuts[m + 1]].clone(), group=group)
+        return
+    q = max(cuts[j + 1] - cuts[j] for j in range(g))
+    dev = table.device if not staged else torch.device(comm_device)
+    mine = torch.zeros((q, table.shape[1]), dtype=table.dtype, device=dev)
+    mine[: cuts[m + 1] - cuts[m]] = table[cuts[m]:cuts[m + 1]].to(dev)
+    full = torch.empty((g * q, table.shape[1]), dtype=table.dtype, device=dev)
+    dist.all_gather_into_tensor(full, mine, group=group)
+    for j in range(g):
+        if j != m:
+            table[cuts[j]:cuts[j + 1]] = full[j * q: j * q + cuts[j + 1] - cuts[j]].to(table.device)
+
+
+class FractionalRunner:
+    """The L-layer stacks (reference model.py:118-129) of the intervals a rank meets under FractionalSharding, each on
+    the rank's slice of the target rows. plans[k] = (plan_u, plan_i) of THIS rank's row slices of interval k
+    (csr_row_slice) against the full source tables; groups[k] = the process group of interval k's members (None on
+    ranks outside it). After run(): out_u / out_i = the rank's slices of sum_l e^l, concatenated in interval order
+    (what RowShardExchange.post takes). Layer outputs are all-gathered inside each interval's group, ascending in
+    the interval — a rank in two groups takes part in both, in the same order as everybody else."""
+
+    def __init__(self, sh: FractionalSharding, n_users: int, n_items: int, d: int, device, groups, dtype=torch.float32,
+                 comm_device=None):
+        self.sh, self.U, self.I, self.d, self.groups = sh, int(n_users), int(n_items), int(d), groups
+        self.comm_device = comm_device
+        self.ks = sh.intervals_of(sh.rank)
+        self.tab_u = {k: torch.zeros((2, self.U, d), dtype=dtype, device=device) for k in self.ks}
+        self.tab_i = {k: torch.zeros((2, self.I, d), dtype=dtype, device=device) for k in self.ks}
+        self.ru = {k: sh.slice_range(self.U, k) for k in self.ks}
+        self.ri = {k: sh.slice_range(self.I, k) for k in self.ks}
+        self.out_u = torch.empty((sum(hi - lo for lo, hi in self.ru.values()), d), dtype=dtype, device=device)
+        self.out_i = torch.empty((sum(hi - lo for lo, hi in self.ri.values()), d), dtype=dtype, device=device)
+
+    def run(self, spmm, plans: dict, emb: dict, n_layers: int, leaky: float):
+        """emb[k] = (u0 [U, d], i0 [I, d]) of every interval this rank meets."""
+        sh = self.sh
+        ou, oi = 0, 0
+        acc = {}
+        for k in self.ks:                       # the rank's slices of the running sums, views into the send buffers
+            (lu, hu), (li, hi) = self.ru[k], self.ri[k]
+            acc[k] = (self.out_u[ou: ou + hu - lu], self.out_i[oi: oi + hi - li])
+            ou, oi = ou + hu - lu, oi + hi - li
+        cur = {k: emb[k] for k in self.ks}
+        for l in range(n_layers):
+            last = l + 1 == n_layers
+            for k in self.ks:
+                (lu, hu), (li, hi) = self.ru[k], self.ri[k]
+                cu, ci = cur[k]
+                nu, ni = self.tab_u[k][l & 1], self.tab_i[k][l & 1]
+                for plan, src, c, lo, hi_, nxt, a in ((plans[k][0], ci, cu, lu, hu, nu, acc[k][0]),
+                                                      (plans[k][1], cu, ci, li, hi, ni, acc[k][1])):
+                    if hi_ > lo:
+                        spmm(plan, src[: plan.n_src], leaky, residual=c[lo:hi_], out=None if last else nxt[lo:hi_],
+                             acc_in=c[lo:hi_] if l == 0 else a, acc_out=a, want_out=not last)
+            if last:
+                break
+            for k in self.ks:                    # ascending k on every rank: no cycle between overlapping groups
+                m = sh.members(k).index(sh.rank)
+                _all_gather_rows(self.tab_u[k][l & 1], sh.cuts(self.U, k), m, self.groups[k], self.comm_device)
+                _all_gather_rows(self.tab_i[k][l & 1], sh.cuts(self.I, k), m, self.groups[k], self.comm_device)
+                cur[k] = (self.tab_u[k][l & 1], self.tab_i[k][l & 1])
+        return self.out_u, self.out_i
 
 
 def csr_row_slice(rowptr, colidx, lo: int, hi: int):
@@ -199,14 +377,14 @@ def exchange_to_row_shards(local_out: torch.Tensor, sh: IntervalSharding, n_rows
     lo, hi = sh.row_range(n_rows)
     x = torch.empty((sh.T, hi - lo, d), dtype=local_out.dtype, device=local_out.device)
     bounds = sh.row_bounds(n_rows)
-    if isinstance(sh, SplitIntervalSharding):
-        # local_out: this member's slice [slice rows, d] of its interval's output. One all-to-all;
+    if isinstance(sh, (SplitIntervalSharding, FractionalSharding)):
+        # local_out: this rank's row slice(s) [rows, d] of its interval output(s). One all-to-all;
         # senders arrive in rank order = (interval, slice) order = the layout of x.
         if mode != "alltoall":
             raise ValueError("split sharding (T < world) exchanges by all-to-all only")
         ins, outs = sh.exchange_splits(n_rows)
-        dist.all_to_all_single(x.view(sh.T * (hi - lo), d), local_out.reshape(-1, d), output_split_sizes=outs,
-                               input_split_sizes=ins, group=group)
+        dist.all_to_all_single(x.view(sh.T * (hi - lo), d), _send_rows(local_out.reshape(-1, d), sh, n_rows),
+                               output_split_sizes=outs, input_split_sizes=ins, group=group)
         return x
     if mode == "alltoall":
         # all_to_all_single per round j: the input is this rank's j-th interval output split by
@@ -237,6 +415,14 @@ def exchange_to_row_shards(local_out: torch.Tensor, sh: IntervalSharding, n_rows
     raise ValueError(f"unknown exchange mode {mode!r}")
 
 
+def _send_rows(rows: torch.Tensor, sh, n_rows: int) -> torch.Tensor:
+    """The rank's slice rows in SEND order (grouped by destination shard). One segment: already so."""
+    if not isinstance(sh, FractionalSharding) or len(sh.intervals_of(sh.rank)) <= 1:
+        return rows
+    pieces = sh.send_order(n_rows)
+    return torch.cat([rows[o:o + n] for o, n in pieces]) if pieces else rows[:0]
+
+
 class RowShardExchange:
     """Incremental form of exchange_to_row_shards(mode="alltoall"): round j is posted as soon as
     the rank's j-th interval output exists (async collective on RCCL's own stream), so it moves
@@ -252,7 +438,7 @@ class RowShardExchange:
         self._empty = torch.empty((0, d), dtype=dtype, device=device)
         self._work = []
         self._posted = 0
-        self._split = sh.exchange_splits(n_rows) if isinstance(sh, SplitIntervalSharding) else None
+        self._split = sh.exchange_splits(n_rows) if isinstance(sh, (SplitIntervalSharding, FractionalSharding)) else None
 
     def post(self, out_j: torch.Tensor | None):
         """out_j [N, d]: this rank's next interval output (None when the rank has no interval in
@@ -264,7 +450,8 @@ class RowShardExchange:
             return
         if self._split is not None:           # T < world: out_j is this member's row slice of its interval
             ins, outs = self._split
-            w = dist.all_to_all_single(self.x.view(sh.T * self.rows_local, self.d), out_j.reshape(-1, self.d),
+            w = dist.all_to_all_single(self.x.view(sh.T * self.rows_local, self.d),
+                                       _send_rows(out_j.reshape(-1, self.d), sh, self.n_rows),
                                        output_split_sizes=outs, input_split_sizes=ins, group=self.group, async_op=True)
             self._work.append(w)
             return
@@ -473,7 +660,7 @@ class ExchangeRowsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, local_out, sh, n_rows, group):
-        if isinstance(sh, SplitIntervalSharding):
+        if isinstance(sh, (SplitIntervalSharding, FractionalSharding)):
             raise NotImplementedError("backward of the row-split exchange (T < world) is not built")
         ctx.sh, ctx.n_rows, ctx.group, ctx.t_loc = sh, n_rows, group, local_out.shape[0]
         return exchange_to_row_shards(local_out.detach().contiguous(), sh, n_rows, group, mode="alltoall")

@@ -60,15 +60,17 @@ def test_four_ranks_match_single_process():
     assert one["final_position_checksum"] == four["final_position_checksum"]
 
 
-def test_fewer_intervals_than_ranks_split_rows_match_single_process():
-    """Gowalla-shaped (T = 3, L = 2) on 4 ranks: one interval is computed by a group of two ranks that
-    split its target rows and all-gather the layer outputs (parallel.SplitIntervalRunner); the ONE
-    all-to-all and the fusion are unchanged. Real kernels, gloo transport, one GPU. (Four ranks: the
-    GPU box allows six processes on the card, and the test runner and the launcher are two of them;
-    T = 5 on 8 ranks runs on the CPU in tests/test_parallel.py.)"""
+@pytest.mark.parametrize("split", ["fractional", "groups"])
+def test_fewer_intervals_than_ranks_split_rows_match_single_process(split):
+    """Gowalla-shaped (T = 3, L = 2) on 4 ranks. fractional (the default): every rank computes a quarter of the
+    intervals' target rows laid end to end — ranks 1 and 2 the tail of one interval and the head of the next — and
+    takes part in the layer all-gathers of both (parallel.FractionalRunner); groups: one interval is computed by a
+    group of two ranks (parallel.SplitIntervalRunner). The ONE all-to-all and the fusion are unchanged. Real kernels,
+    gloo transport, one GPU. (Four ranks: the GPU box allows six processes on the card, and the test runner and the
+    launcher are two of them; T = 5 on 8 ranks runs on the CPU in tests/test_parallel.py.)"""
     common = ["--workload", "gowalla-shaped", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
     one = _run([sys.executable, "bench.py"] + common)
-    six = _run([sys.executable, "bench.py", "--gpus", "4",
+    six = _run([sys.executable, "bench.py", "--gpus", "4", "--split", split,
                 "--dist-backend", "gloo"] + common)
     assert one["config"]["intervals_total"] == six["config"]["intervals_total"] == 3
     assert "T < world" in six["config"]["partitioning"]

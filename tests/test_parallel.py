@@ -165,7 +165,7 @@ def _split_worker(rank, world, port, T, weights, q):
     try:
         U, I, d, L = 23, 17, 16, 3
         mats, ue, ie, p = _problem(T, U, I, d)
-        sh = make_sharding(T, world, rank, weights)
+        sh = make_sharding(T, world, rank, weights, split="groups")
         assert isinstance(sh, SplitIntervalSharding) and sh.rounds == 1
         groups = [dist.new_group(sh.members(k)) for k in range(T)]      # every rank creates every group
         k = sh.interval
@@ -293,3 +293,92 @@ def test_distributed_backward_matches_single_process(world, T):
             np.testing.assert_allclose(g_leaf, leaf.grad.numpy()[mine], rtol=1e-9, atol=1e-12)
         for k in p:
             np.testing.assert_allclose(g_p[k], p[k].grad.numpy(), rtol=1e-9, atol=1e-11)
+
+
+# ---- fewer intervals than ranks, edge-balanced: a rank takes the tail rows of one interval and the head rows of the next
+def _fractional_worker(rank, world, port, T, weights, q):
+    from sa_gnn_amd.graph import csr_arrays, transpose
+    from sa_gnn_amd.parallel import FractionalRunner, FractionalSharding, csr_row_slice, make_sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        U, I, d, L = 23, 17, 16, 3
+        mats, ue, ie, p = _problem(T, U, I, d)
+        sh = make_sharding(T, world, rank, weights)
+        assert isinstance(sh, FractionalSharding) and sh.rounds == 1
+        groups = [dist.new_group(sh.members(k)) for k in range(T)]      # every rank creates every group
+        plans, emb = {}, {}
+        for k in sh.intervals_of(rank):
+            rp_u, ci_u = csr_arrays(mats[k])
+            rp_i, ci_i = csr_arrays(transpose(mats[k]))
+            (lu, hu), (li, hi) = sh.slice_range(U, k), sh.slice_range(I, k)
+            plans[k] = (_CpuPlan(*csr_row_slice(rp_u, ci_u, lu, hu), hu - lu, I), _CpuPlan(*csr_row_slice(rp_i, ci_i, li, hi), hi - li, U))
+            emb[k] = (torch.from_numpy(ue[k]), torch.from_numpy(ie[k]))
+        run = FractionalRunner(sh, U, I, d, torch.device("cpu"), {k: groups[k] for k in sh.intervals_of(rank)})
+        acc_u, acc_i = run.run(_cpu_spmm, plans, emb, L, 0.5)
+        res = {}
+        for tag, acc, n_rows in (("u", acc_u, U), ("i", acc_i, I)):
+            ex = RowShardExchange(sh, n_rows, d, torch.device("cpu"))
+            ex.post(acc)
+            x = ex.wait_round(0).clone()
+            assert torch.equal(ex.finish(), x)
+            assert torch.equal(exchange_to_row_shards(acc, sh, n_rows), x)      # blocking form, same splits
+            lo, hi_ = sh.row_range(n_rows)
+            assert x.shape == (T, hi_ - lo, d)
+            fused = O.interval_fusion(x.permute(1, 0, 2).numpy(), p, 4) if hi_ > lo else np.zeros((0, d), np.float32)
+            res[tag] = gather_fused(torch.from_numpy(fused), sh, n_rows).numpy()
+        q.put((rank, res["u"], res["i"]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T,weights", [(8, 5, [72280, 78997, 79692, 78096, 45651]), (4, 3, None), (3, 1, None),
+                                             (8, 3, [5, 1, 1]), (6, 4, [1, 30, 1, 1])])
+def test_fractional_sharding_matches_single_process(world, T, weights):
+    """T < world, edge-balanced (Amazon's T = 5 on 8 ranks: 44 k edges on every rank instead of 72 k on the busiest):
+    ranks take fractional stretches of the concatenated intervals, all-gather layer outputs inside every interval's
+    group (uneven slices, a rank in two groups), and feed ONE all-to-all; the fused embeddings of both node types
+    equal the single-process oracle on every rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fractional_worker, args=(r, world, port, T, weights, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    mats, ue, ie, p = _problem(T, 23, 17, 16)
+    uv, iv = O.gnn_stack(ue, ie, [O.trans_to_lsts(m)[0] for m in mats],
+                         [O.trans_to_lsts(O.transpose(m))[0] for m in mats], 3, 0.5)
+    want_u, want_i = O.interval_fusion(uv, p, 4), O.interval_fusion(iv, p, 4)
+    for _, got_u, got_i in results:
+        np.testing.assert_allclose(got_u, want_u, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(got_i, want_i, rtol=1e-5, atol=1e-5)
+
+
+def test_fractional_sharding_maps_balance_edges():
+    from sa_gnn_amd.parallel import FractionalSharding, SplitIntervalSharding
+    w = [72280, 78997, 79692, 78096, 45651]
+    shs = [FractionalSharding(5, 8, r, w) for r in range(8)]
+    assert [s.intervals_of(s.rank) for s in shs] == [[0], [0, 1], [1], [1, 2], [2], [2, 3], [3, 4], [4]]
+    assert shs[0].members(1) == [1, 2, 3] and shs[0].members(4) == [6, 7]
+    for n_rows in (11199, 30821, 7, 1):
+        for k in range(5):                                           # member slices tile [0, n_rows)
+            c = shs[0].cuts(n_rows, k)
+            assert c[0] == 0 and c[-1] == n_rows and all(a <= b for a, b in zip(c, c[1:]))
+            assert [shs[r].slice_range(n_rows, k) for r in shs[0].members(k)] == list(zip(c, c[1:]))
+        assert sum(sum(s.exchange_splits(n_rows)[0]) for s in shs) == 5 * n_rows == sum(sum(s.exchange_splits(n_rows)[1]) for s in shs)
+        for s in shs:                                                # the send permutation covers the rank's rows once
+            pieces = s.send_order(n_rows)
+            tot = sum(hi - lo for lo, hi in (s.slice_range(n_rows, k) for k in s.intervals_of(s.rank)))
+            assert sorted(i for o, n in pieces for i in range(o, o + n)) == list(range(tot))
+    # edges per rank (rows of an interval taken as equally heavy): 44.3 k on every rank; whole-rank groups: 72 k on the busiest
+    U = 11199
+    load = [sum((s.slice_range(U, k)[1] - s.slice_range(U, k)[0]) / U * w[k] for k in s.intervals_of(s.rank)) for s in shs]
+    assert max(load) <= 1.001 * sum(w) / 8
+    grp = [SplitIntervalSharding(5, 8, r, w) for r in range(8)]
+    load_g = [(g.slice_range(U)[1] - g.slice_range(U)[0]) / U * w[g.interval] for g in grp]
+    assert max(load_g) >= 1.6 * sum(w) / 8
