@@ -58,7 +58,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // which they are issued and the MFMA gap each one goes to come from a list scheduler over their dependency
 // graph (tools/gen_lstm_schedule.py): at most one transcendental per gap, an even share of the issue cycles,
 // and nothing reads a result of its own gap.
-constexpr int kGateOps = 86, kXOps = 16;
+constexpr int kGateOps = 118, kXOps = 16;
 #include "lstm_f16_schedule.inc"
 template <int NM, bool XO>
 __host__ __device__ constexpr int sched_start(int i) {
@@ -252,93 +252,68 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
       auto gate_op = [&](auto pb_c, auto k_c) {
         constexpr int PB = decltype(pb_c)::value, K = decltype(k_c)::value;
         const int row = PB * 16 + m_;
-        // Element-wise steps run on PAIRS of hidden units (v_pk_fma / v_pk_add / v_pk_mul: two fp32 operations per lane
-        // and instruction at 5.1 cycles against 2 x 4.7, tools/microbench/pk_rate.hip): a lane's four hidden units are
-        // the two halves of its accumulator registers, so the pairs exist without a move. Only the transcendentals
-        // and the f16 split of h stay per element.
         if constexpr (K == 0) {
           const int e_td = (row * t + ts) * D + hid;
           if constexpr (DROP) dv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, e_td * 4, 0, 0));
-        } else if constexpr (K < 9) {           // the two accumulators joined: t = head + 2^-12 residual
-          constexpr int k = K - 1, g = k >> 1, pp = k & 1;
-          const f32x2 j = f32x2{gl[g][2 * pp], gl[g][2 * pp + 1]} * kLoInv + f32x2{ga[g][2 * pp], ga[g][2 * pp + 1]};
-          ga[g][2 * pp] = j.x, ga[g][2 * pp + 1] = j.y;
-        } else if constexpr (K < 25) {
-          constexpr int k = K - 9, g = k >> 2, r = k & 3;
-          tt[g][r] = __builtin_amdgcn_exp2f(ga[g][r]);
+        } else if constexpr (K < 17) {          // the two accumulators joined: t = head + 2^-12 residual
+          constexpr int k = K - 1, g = k >> 2, r = k & 3;
+          ga[g][r] = fmaf(gl[g][r], kLoInv, ga[g][r]);
         } else if constexpr (K < 33) {
-          constexpr int k = K - 25, g = k >> 1, pp = k & 1;
-          const f32x2 a = f32x2{tt[g][2 * pp], tt[g][2 * pp + 1]} + 1.f;
-          tt[g][2 * pp] = a.x, tt[g][2 * pp + 1] = a.y;
+          constexpr int k = K - 17, g = k >> 2, r = k & 3;
+          tt[g][r] = __builtin_amdgcn_exp2f(ga[g][r]);
         } else if constexpr (K < 49) {
           constexpr int k = K - 33, g = k >> 2, r = k & 3;
+          tt[g][r] = 1.f + tt[g][r];
+        } else if constexpr (K < 65) {
+          constexpr int k = K - 49, g = k >> 2, r = k & 3;
           tt[g][r] = __builtin_amdgcn_rcpf(tt[g][r]);       // sigmoid(i), 1/(1+e^2j), sigmoid(f), sigmoid(o)
-        } else if constexpr (K < 51) {
-          constexpr int pp = K - 49;
-          const f32x2 a = f32x2{tt[1][2 * pp], tt[1][2 * pp + 1]} * -2.f + 1.f;     // tanh(j)
-          tt[1][2 * pp] = a.x, tt[1][2 * pp + 1] = a.y;
-        } else if constexpr (K < 53) {
-          constexpr int pp = K - 51;
-          const f32x2 a = f32x2{tt[0][2 * pp], tt[0][2 * pp + 1]} * f32x2{tt[1][2 * pp], tt[1][2 * pp + 1]};
-          pr[2 * pp] = a.x, pr[2 * pp + 1] = a.y;
-        } else if constexpr (K < 55) {
-          constexpr int pp = K - 53;
-          const f32x2 a = f32x2{c[PB][2 * pp], c[PB][2 * pp + 1]} * f32x2{tt[2][2 * pp], tt[2][2 * pp + 1]} + f32x2{pr[2 * pp], pr[2 * pp + 1]};
-          cn[2 * pp] = a.x, cn[2 * pp + 1] = a.y;
-        } else if constexpr (K < 57) {
-          constexpr int pp = K - 55;
-          const f32x2 a = f32x2{cn[2 * pp], cn[2 * pp + 1]} * (2.f * kL2E);
-          u[2 * pp] = a.x, u[2 * pp + 1] = a.y;
-        } else if constexpr (K < 61) {
-          u[K - 57] = __builtin_amdgcn_exp2f(u[K - 57]);
-        } else if constexpr (K < 63) {
-          constexpr int pp = K - 61;
-          const f32x2 a = f32x2{u[2 * pp], u[2 * pp + 1]} + 1.f;
-          u[2 * pp] = a.x, u[2 * pp + 1] = a.y;
-        } else if constexpr (K < 67) {
-          u[K - 63] = __builtin_amdgcn_rcpf(u[K - 63]);
         } else if constexpr (K < 69) {
-          constexpr int pp = K - 67;
-          const f32x2 a = f32x2{u[2 * pp], u[2 * pp + 1]} * -2.f + 1.f;              // tanh(c')
-          u[2 * pp] = a.x, u[2 * pp + 1] = a.y;
-        } else if constexpr (K < 71) {
-          constexpr int pp = K - 69;
-          const f32x2 a = f32x2{u[2 * pp], u[2 * pp + 1]} * f32x2{tt[3][2 * pp], tt[3][2 * pp + 1]};
-          hn[2 * pp] = a.x, hn[2 * pp + 1] = a.y;
+          tt[1][K - 65] = fmaf(-2.f, tt[1][K - 65], 1.f);     // tanh(j)
         } else if constexpr (K < 73) {
-          constexpr int pp = K - 71;
-          if constexpr (DROP) {
-            const f32x2 a = f32x2{hn[2 * pp], hn[2 * pp + 1]} * f32x2{dv[2 * pp], dv[2 * pp + 1]};
-            hv[2 * pp] = a.x, hv[2 * pp + 1] = a.y;
-          } else {
-            hv[2 * pp] = hn[2 * pp], hv[2 * pp + 1] = hn[2 * pp + 1];
-          }
-        } else if constexpr (K == 73) {
+          pr[K - 69] = tt[0][K - 69] * tt[1][K - 69];
+        } else if constexpr (K < 77) {
+          cn[K - 73] = fmaf(c[PB][K - 73], tt[2][K - 73], pr[K - 73]);
+        } else if constexpr (K < 81) {
+          u[K - 77] = cn[K - 77] * (2.f * kL2E);
+        } else if constexpr (K < 85) {
+          u[K - 81] = __builtin_amdgcn_exp2f(u[K - 81]);
+        } else if constexpr (K < 89) {
+          u[K - 85] = 1.f + u[K - 85];
+        } else if constexpr (K < 93) {
+          u[K - 89] = __builtin_amdgcn_rcpf(u[K - 89]);
+        } else if constexpr (K < 97) {
+          u[K - 93] = fmaf(-2.f, u[K - 93], 1.f);             // tanh(c')
+        } else if constexpr (K < 101) {
+          hn[K - 97] = u[K - 97] * tt[3][K - 97];
+        } else if constexpr (K < 105) {
+          if constexpr (DROP) hv[K - 101] = hn[K - 101] * dv[K - 101];
+          else hv[K - 101] = hn[K - 101];
+        } else if constexpr (K == 105) {
           w0[0] = head2(hn[0], hn[1]);
-        } else if constexpr (K == 74) {
+        } else if constexpr (K == 106) {
           w0[1] = head2(hn[2], hn[3]);
-        } else if constexpr (K < 79) {
-          constexpr int i = K - 75;
+        } else if constexpr (K < 111) {
+          constexpr int i = K - 107;
           r1[i] = resid<(i & 1)>(w0[i >> 1], hn[i]);
-        } else if constexpr (K == 79) {
+        } else if constexpr (K == 111) {
           w1[0] = tail_lo(r1[0], k4096);
-        } else if constexpr (K == 80) {
+        } else if constexpr (K == 112) {
           w1[0] = tail_hi(w1[0], r1[1], k4096);
-        } else if constexpr (K == 81) {
+        } else if constexpr (K == 113) {
           w1[1] = tail_lo(r1[2], k4096);
-        } else if constexpr (K == 82) {
+        } else if constexpr (K == 114) {
           w1[1] = tail_hi(w1[1], r1[3], k4096);
           hoff = row * (D * 2) + (((hid >> 3) ^ swz<D>(row)) << 4) + ((hid >> 2) & 1) * 8;
-        } else if constexpr (K == 83) {
+        } else if constexpr (K == 115) {
           // always written: after the last step nothing reads it (no branch in the interleaved stream)
           *reinterpret_cast<i32x2*>(Hnxt + hoff) = i32x2{w0[0], w0[1]};
           *reinterpret_cast<i32x2*>(Hnxt + PLANE + hoff) = i32x2{w1[0], w1[1]};
-        } else if constexpr (K == 84) {
+        } else if constexpr (K == 116) {
           const i32x4 hvv = {__builtin_bit_cast(int, hv[0]), __builtin_bit_cast(int, hv[1]), __builtin_bit_cast(int, hv[2]),
                              __builtin_bit_cast(int, hv[3])};
           __builtin_amdgcn_raw_buffer_store_b128(hvv, rs_h, (row * (int)ld_h + ts * D + hid) * 4, 0, 0);
           c[PB] = f32x4{cn[0], cn[1], cn[2], cn[3]};
-        } else if constexpr (K == 85) {
+        } else if constexpr (K == 117) {
           if constexpr (SAVE) {
             const int e_td = (row * t + ts) * D + hid;
             const int go_ = (row * t + ts) * NC + hid;

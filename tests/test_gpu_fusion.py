@@ -133,3 +133,24 @@ def test_fusion_golden(dev, d):
     np.testing.assert_allclose(ops.interval_fusion(uv, pd, 16).cpu().numpy(), g[f"d{d}/final_user"], rtol=RTOL, atol=ATOL)
     iv = torch.from_numpy(g[f"d{d}/item_vector"]).to(dev)
     np.testing.assert_allclose(ops.interval_fusion(iv, pd, 16).cpu().numpy(), g[f"d{d}/final_item"], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("d,t", [(64, 4), (32, 16), (128, 3), (64, 16)])
+def test_a_rows_result_does_not_depend_on_its_position_in_a_tile(dev, d, t):
+    """The persistent kernels walk 96-row (LSTM) / 64-row (attention) tiles; the multi-GPU pipeline feeds them row
+    shards and row chunks, so a node sits at a different tile position at every world size. Its h and its fused row
+    must be BIT-identical wherever it sits (a hand-scheduled kernel whose per-tile instances were compiled to
+    different instruction forms would break this: measured once with packed gate math)."""
+    from sa_gnn_amd import ops
+    from sa_gnn_amd.model import random_fusion_params
+    n = 960
+    g = torch.Generator(device=dev).manual_seed(3)
+    x = torch.rand((n, t, d), generator=g, device=dev) * 0.06 - 0.03
+    p = random_fusion_params(d, dev, 8)
+    att = lambda h: ops.ln_mhsa_mean(h, p["ln_gamma"], p["ln_beta"], p["Wq"], p["bq"], p["Wk"], p["bk"], p["Wv"], p["bv"], 16)   # noqa: E731
+    h = ops.lstm_fwd(x, p["lstm_W"], p["lstm_b"])
+    f = att(h)
+    for off in (1, 2, 15, 30, 96, 101):
+        h2 = ops.lstm_fwd(x[off:].contiguous(), p["lstm_W"], p["lstm_b"])
+        assert torch.equal(h2, h[off:]), f"LSTM rows move with the tile offset {off}"
+        assert torch.equal(att(h2), f[off:]), f"attention rows move with the tile offset {off}"

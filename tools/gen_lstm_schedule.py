@@ -25,48 +25,50 @@ K_X = 16
 
 
 class Ops:
-    """Operation numbers of `gate_op` in lstm_f16_kernel.h (4 hidden units per lane, element-wise steps on pairs)."""
-    def __init__(self):
-        self.join, self.exp, self.add1, self.rcp = 1, 9, 25, 33          # 8 pk, 16 trans, 8 pk, 16 trans
-        self.tj, self.pr, self.cn, self.um = 49, 51, 53, 55                 # 2 pk each
-        self.ue, self.ua, self.ur, self.ut = 57, 61, 63, 67                 # 4 trans, 2 pk, 4 trans, 2 pk
-        self.hn, self.hv, self.head, self.res, self.tail = 69, 71, 73, 75, 79
-        self.write, self.store, self.save, self.n_gate = 83, 84, 85, 86
-        self.trans = set(range(9, 25)) | set(range(33, 49)) | set(range(57, 61)) | set(range(63, 67))
-        self.packed = (set(range(1, 9)) | set(range(25, 33)) | set(range(49, 57)) | set(range(61, 63)) | set(range(67, 73)))
+    def __init__(self, u):
+        self.u = u
+        self.c, self.e, self.a, self.r = 1, 1 + 4 * u, 1 + 8 * u, 1 + 12 * u
+        t0 = 1 + 16 * u
+        (self.tj, self.pr, self.cn, self.um, self.ue, self.ua, self.ur, self.ut, self.hn, self.hv) = (t0 + i * u for i in range(10))
+        self.head = t0 + 10 * u
+        self.res = self.head + u // 2
+        self.tail = self.res + u
+        self.write = self.tail + u
+        self.store = self.write + 1
+        self.save = self.write + 2
+        self.n_gate = self.write + 3
+        self.trans = (set(range(self.e, self.e + 4 * u)) | set(range(self.r, self.r + 4 * u)) |
+                      set(range(self.ue, self.ue + u)) | set(range(self.ur, self.ur + u)))
 
 
-def build(xpasses):
-    o = Ops()
+def build(u, xpasses):
+    o = Ops(u)
     n = o.n_gate + xpasses * K_X
     deps = {k: set() for k in range(n)}
-    for g in range(4):
-        for r in range(4):
-            e = o.exp + 4 * g + r
-            deps[e].add(o.join + 2 * g + r // 2)
-            deps[o.add1 + 2 * g + r // 2].add(e)
-            deps[o.rcp + 4 * g + r].add(o.add1 + 2 * g + r // 2)
-    for p in range(2):
-        rc = lambda g: {o.rcp + 4 * g + 2 * p, o.rcp + 4 * g + 2 * p + 1}     # noqa: E731
-        deps[o.tj + p] |= rc(1)
-        deps[o.pr + p] |= rc(0) | {o.tj + p}
-        deps[o.cn + p] |= rc(2) | {o.pr + p}
-        deps[o.um + p].add(o.cn + p)
-        for r in (2 * p, 2 * p + 1):
-            deps[o.ue + r].add(o.um + p)
-            deps[o.ua + p].add(o.ue + r)
-            deps[o.ur + r].add(o.ua + p)
-            deps[o.ut + p].add(o.ur + r)
-        deps[o.hn + p] |= {o.ut + p} | rc(3)
-        deps[o.hv + p] |= {o.hn + p, 0}
-        deps[o.head + p].add(o.hn + p)
-        for r in (2 * p, 2 * p + 1):
-            deps[o.res + r] |= {o.head + p, o.hn + p}
-            deps[o.tail + r].add(o.res + r)
-        deps[o.tail + 2 * p + 1].add(o.tail + 2 * p)          # v_fma_mixhi_f16 into the register v_fma_mixlo_f16 wrote
-    deps[o.write] |= {o.head, o.head + 1} | set(range(o.tail, o.tail + 4))
-    deps[o.store] |= {o.hv, o.hv + 1, o.cn, o.cn + 1}
-    deps[o.save] |= set(range(o.rcp, o.rcp + 16)) | {o.tj, o.tj + 1, o.cn, o.cn + 1}
+    for k in range(4 * u):
+        deps[o.e + k].add(o.c + k)
+        deps[o.a + k].add(o.e + k)
+        deps[o.r + k].add(o.a + k)
+    for i in range(u):
+        deps[o.tj + i].add(o.r + 1 * u + i)
+        deps[o.pr + i] |= {o.r + i, o.tj + i}
+        deps[o.cn + i] |= {o.r + 2 * u + i, o.pr + i}
+        deps[o.um + i].add(o.cn + i)
+        deps[o.ue + i].add(o.um + i)
+        deps[o.ua + i].add(o.ue + i)
+        deps[o.ur + i].add(o.ua + i)
+        deps[o.ut + i].add(o.ur + i)
+        deps[o.hn + i] |= {o.ut + i, o.r + 3 * u + i}
+        deps[o.hv + i] |= {o.hn + i, 0}
+        deps[o.res + i] |= {o.head + i // 2, o.hn + i}
+        deps[o.tail + i].add(o.res + i)
+        if i % 2:
+            deps[o.tail + i].add(o.tail + i - 1)          # v_fma_mixhi_f16 into the register v_fma_mixlo_f16 wrote
+    for j in range(u // 2):
+        deps[o.head + j] |= {o.hn + 2 * j, o.hn + 2 * j + 1}
+    deps[o.write] |= set(range(o.head, o.head + u // 2)) | set(range(o.tail, o.tail + u))
+    deps[o.store] |= set(range(o.hv, o.hv + u)) | set(range(o.cn, o.cn + u))
+    deps[o.save] |= set(range(o.r, o.r + 4 * u)) | set(range(o.tj, o.tj + u)) | set(range(o.cn, o.cn + u))
     for p in range(xpasses):
         b = o.n_gate + p * K_X
         for i in range(4):
@@ -80,13 +82,13 @@ def build(xpasses):
         deps[b + 13].add(b + 11)                          # ... its bits - 1
         deps[b + 14].add(b + 13)                          # ... into the running min
         deps[b + 15] |= {b + 0, b + 1, b + 7, b + 9, b + 11}
-    cost = {k: (8 if k in o.trans else 5 if k in o.packed else 4) for k in range(n)}
+    cost = {k: (8 if k in o.trans else 4) for k in range(n)}
     cost[o.save] = 20
     return n, deps, cost, o.trans
 
 
-def schedule(nm, xpasses):
-    n, deps, cost, trans = build(xpasses)
+def schedule(u, nm, xpasses):
+    n, deps, cost, trans = build(u, xpasses)
     succ = {k: set() for k in range(n)}
     for k, ds in deps.items():
         for d in ds:
@@ -150,13 +152,16 @@ def schedule(nm, xpasses):
 
 
 def main():
-    print("// Generated by tools/gen_lstm_schedule.py — do not edit. Issue order of the gate-math operations of one batch")
+    u = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    xp = 2 if u == 4 else 1
+    gaps = (48, 24, 12) if u == 4 else (24, 12, 6)
+    print(f"// Generated by tools/gen_lstm_schedule.py {u} — do not edit. Issue order of the gate-math operations of one batch")
     print("// tile and the first position of each MFMA gap's share (see `step` in the kernel header).")
-    for nm in (48, 24, 12):
+    for nm in gaps:
         for with_x in (0, 1):
-            order, starts, worst, tr, last = schedule(nm, 2 if with_x else 0)
+            order, starts, worst, tr, last = schedule(u, nm, xp if with_x else 0)
             tag = f"{nm}{'X' if with_x else ''}"
-            print(f"// {nm} gaps, {'with' if with_x else 'without'} the x passes: {len(order)} operations, heaviest gap {worst} issue cycles, "
+            print(f"// {nm} gaps, {'with' if with_x else 'without'} the x pass{'es' if xp > 1 else ''}: {len(order)} operations, heaviest gap {worst} issue cycles, "
                   f"<= {tr} transcendentals per gap, {last} operations in the last gap")
             print(f"constexpr int kOrder{tag}[{len(order)}] = {{{', '.join(map(str, order))}}};")
             print(f"constexpr int kStart{tag}[{len(starts)}] = {{{', '.join(map(str, starts))}}};")
