@@ -56,11 +56,11 @@ int ln_mhsa_mean_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, in
                        const float* gamma, const float* beta, float eps, int apply_ln, const float* Wq,
                        const float* bq, const float* Wk, const float* bk, const float* Wv, const float* bv,
                        float* out, int64_t ld_out, hipStream_t s);
-// lstm_split128.hip: d = 128, one launch per step, hidden slices across workgroups (drop must be NULL)
+// lstm_split128.hip: d = 128, one launch per step, hidden slices across workgroups (drop: training form only)
 bool lstm_split128_supported(int d);
 int lstm_fwd_split128(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, const float* W, const float* b,
-                      float forget_bias, float* h, int64_t ld_h, float* gates_out, float* c_out, const float* h_init,
-                      int64_t ld_hi, const float* c_init, float* c_final, hipStream_t s);
+                      float forget_bias, const float* drop, float* h, int64_t ld_h, float* gates_out, float* c_out,
+                      const float* h_init, int64_t ld_hi, const float* c_init, float* c_final, hipStream_t s);
 bool force_f32_mfma();  // the calling thread chose SAGNN_ENGINE_F32 (sagnn_set_engine): the exact-fp32 MFMA kernels
 bool mhsa_mfma_supported(int d, int t, int heads);
 int ln_mhsa_mean_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads,

@@ -378,8 +378,8 @@ extern "C" int sagnn_lstm_fwd_state_f32(const float* x, int64_t ld_n, int64_t ld
                                 ld_hi, c_init, c_final, s);
   if (sagnn::lstm_split128_supported(d) && vec_ok && !drop_scale && (ld_h & 3) == 0 && sagnn::aligned16(h) &&
       !sagnn::force_valu() && !sagnn::force_f32_mfma())
-    return sagnn::lstm_fwd_split128(x, ld_n, ld_t, n, t, W, b, forget_bias, h, ld_h, nullptr, nullptr, h_init, ld_hi, c_init,
-                                    c_final, s);
+    return sagnn::lstm_fwd_split128(x, ld_n, ld_t, n, t, W, b, forget_bias, nullptr, h, ld_h, nullptr, nullptr, h_init, ld_hi,
+                                    c_init, c_final, s);
   return sagnn::lstm_fwd_valu(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, nullptr, nullptr, h_init,
                               ld_hi, c_init, c_final, s);
 }
@@ -558,10 +558,10 @@ extern "C" int sagnn_lstm_fwd_train_f32(const float* x, int64_t ld_n, int64_t ld
   if (sagnn::lstm_mfma_supported(d) && vec_ok && !sagnn::force_valu())
     return sagnn::lstm_fwd_mfma(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, gates, cell, nullptr, 0,
                                 nullptr, nullptr, static_cast<hipStream_t>(stream));
-  if (sagnn::lstm_split128_supported(d) && vec_ok && !drop_scale && (ld_h & 3) == 0 && sagnn::aligned16(h) &&
-      !sagnn::force_valu() && !sagnn::force_f32_mfma())
-    return sagnn::lstm_fwd_split128(x, ld_n, ld_t, n, t, W, b, forget_bias, h, ld_h, gates, cell, nullptr, 0, nullptr, nullptr,
-                                    static_cast<hipStream_t>(stream));
+  if (sagnn::lstm_split128_supported(d) && vec_ok && (ld_h & 3) == 0 && sagnn::aligned16(h) &&
+      (!drop_scale || sagnn::aligned16(drop_scale)) && !sagnn::force_valu() && !sagnn::force_f32_mfma())
+    return sagnn::lstm_fwd_split128(x, ld_n, ld_t, n, t, W, b, forget_bias, drop_scale, h, ld_h, gates, cell, nullptr, 0, nullptr,
+                                    nullptr, static_cast<hipStream_t>(stream));
   return sagnn::lstm_fwd_valu(x, ld_n, ld_t, n, t, d, W, b, forget_bias, drop_scale, h, ld_h, gates, cell, nullptr, 0,
                               nullptr, nullptr, static_cast<hipStream_t>(stream));
 }

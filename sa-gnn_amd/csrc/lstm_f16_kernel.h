@@ -437,49 +437,74 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
       // fmaf chains, thread per (row, hidden unit), h and c of the tile in LDS. Never taken on sane data.
       float* const hs = reinterpret_cast<float*>(lds);     // [2][kRows][D]
       float* const cs = hs + 2 * kRows * D;                 // [kRows][D]
+      float* const xs = cs + kRows * D;                     // [kRows][D]: x_t of the tile (the four tiles fill the image space exactly)
       for (int idx = tid; idx < kRows * D; idx += NT) {
         const int r = idx / D, uu = idx - r * D;
         const bool live = r < rows_valid;
         hs[idx] = (h_init && live) ? h_init[(row0 + r) * ld_hi + uu] : 0.f;
         cs[idx] = (c_init && live) ? c_init[(row0 + r) * D + uu] : 0.f;
       }
-      __syncthreads();
+      // a thread owns ONE hidden unit (uu = tid % D: NT is a multiple of D) of RPT rows (r0, r0 + NT / D, ...): the four
+      // weights of a k serve all its rows — one pass over W per step instead of one per (row, unit) pair, which made a
+      // single redone tile cost 2 ms (Amazon-shaped training hits it once the L = 3 hub rows grow past 32768)
+      constexpr int RSTEP = NT / D, RPT = kRows / RSTEP;
+      static_assert(NT % D == 0 && kRows % RSTEP == 0, "one hidden unit per thread");
+      const int uu = tid % D, r0 = tid / D;
       for (int ts = 0; ts < t; ++ts) {
         const float* const hc = hs + (ts & 1) * kRows * D;
         float* const hnx = hs + ((ts & 1) ^ 1) * kRows * D;
-        for (int idx = tid; idx < rows_valid * D; idx += NT) {
-          const int r = idx / D, uu = idx - r * D;
-          float a[4];
+        __syncthreads();
+        for (int idx = tid; idx < kRows * D; idx += NT) {
+          const int r = idx / D, c_ = idx - r * D;
+          xs[idx] = r < rows_valid ? x[(row0 + r) * ld_n + (int64_t)ts * ld_t + c_] : 0.f;
+        }
+        __syncthreads();
+        float a[RPT][4];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) a[g] = bias[g * D + uu] + (g == 2 ? forget_bias : 0.f);
-          const float* const xrow = x + (row0 + r) * ld_n + (int64_t)ts * ld_t;
-          for (int k = 0; k < D; ++k) {
-            const float xv = xrow[k];
+        for (int j = 0; j < RPT; ++j)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) a[g] = fmaf(xv, W[(size_t)k * NC + g * D + uu], a[g]);
+          for (int g = 0; g < 4; ++g) a[j][g] = bias[g * D + uu] + (g == 2 ? forget_bias : 0.f);
+        for (int half = 0; half < 2; ++half) {
+          const float* const src = half ? hc : xs;
+          for (int k = 0; k < D; k += 4) {
+            float w[4][4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) w[kk][g] = W[(size_t)(half * D + k + kk) * NC + g * D + uu];
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+              const float4 v = *reinterpret_cast<const float4*>(src + (r0 + j * RSTEP) * D + k);
+              const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) a[j][g] = fmaf(vv[kk], w[kk][g], a[j][g]);
+            }
           }
-          for (int k = 0; k < D; ++k) {
-            const float hv = hc[r * D + k];
+        }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) a[g] = fmaf(hv, W[(size_t)(D + k) * NC + g * D + uu], a[g]);
-          }
+        for (int j = 0; j < RPT; ++j) {
+          const int r = r0 + j * RSTEP, idx = r * D + uu;
           // tanhf, not the fast path's 1 - 2 / (1 + 2^t): a tile comes here also because a row is tiny as a whole, and
           // such a row's h is as small as its x — only a tanh that is relatively accurate near zero keeps it
-          const float gi = sigmoid_e2(a[0]), gj = tanhf(a[1]), gf = sigmoid_e2(a[2]), go = sigmoid_e2(a[3]);
+          const float gi = sigmoid_e2(a[j][0]), gj = tanhf(a[j][1]), gf = sigmoid_e2(a[j][2]), go = sigmoid_e2(a[j][3]);
           const float cnew = fmaf(cs[idx], gf, gi * gj);
           const float hnew = tanhf(cnew) * go;
           cs[idx] = cnew;
           hnx[idx] = hnew;
-          const int64_t e_td = ((row0 + r) * t + ts) * D + uu;
-          h_out[(row0 + r) * ld_h + (int64_t)ts * D + uu] = DROP ? hnew * drop[e_td] : hnew;
-          if constexpr (SAVE) {
-            float* const gp = gates_out + ((row0 + r) * t + ts) * NC + uu;
-            gp[0] = gi, gp[D] = gj, gp[2 * D] = gf, gp[3 * D] = go;
-            c_out[e_td] = cnew;
+          if (r < rows_valid) {
+            const int64_t e_td = ((row0 + r) * t + ts) * D + uu;
+            h_out[(row0 + r) * ld_h + (int64_t)ts * D + uu] = DROP ? hnew * drop[e_td] : hnew;
+            if constexpr (SAVE) {
+              float* const gp = gates_out + ((row0 + r) * t + ts) * NC + uu;
+              gp[0] = gi, gp[D] = gj, gp[2 * D] = gf, gp[3 * D] = go;
+              c_out[e_td] = cnew;
+            }
           }
         }
-        __syncthreads();
       }
+      __syncthreads();
       if (c_final)
         for (int idx = tid; idx < rows_valid * D; idx += NT) c_final[row0 * D + idx] = cs[idx];
       __syncthreads();

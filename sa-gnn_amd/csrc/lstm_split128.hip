@@ -19,8 +19,8 @@
 //   * c_t is kept in the caller's h buffer one interval AHEAD (slot ts + 1 is free until step ts + 1
 //     writes h there; the same lane reads c and then writes h at those addresses), so the entry needs no
 //     workspace; with saved cell states (training) it is read from / written to them instead.
-// Output dropout is not offered here (the recurrent h would need a second copy): callers with a mask use
-// the VALU kernel. Reference: model.py:135-146, TF 1.14 BasicLSTMCell (see lstm_f16_kernel.h).
+// Output dropout (training form only): the emitted h is h * mask and the next launch re-makes the un-dropped h from the saved
+// cell state and o gate instead of keeping a second copy. Reference: model.py:135-146, TF 1.14 BasicLSTMCell (see lstm_f16_kernel.h).
 #include <type_traits>
 
 #include "common.h"
@@ -45,7 +45,12 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
     const float* __restrict__ x_t, int64_t ld_x, const float* __restrict__ h_prev, int64_t ld_hp,
     const float* c_prev, int64_t ld_cp, const float* __restrict__ W, const float* __restrict__ bias,
     float forget_bias, float* h_out, int64_t ld_h, float* c_out, int64_t ld_c,
-    float* __restrict__ gates_out, int64_t ld_g, int64_t n, int64_t n_tiles, unsigned int* __restrict__ redo_ctr) {
+    float* __restrict__ gates_out, int64_t ld_g, int64_t n, int64_t n_tiles, unsigned int* __restrict__ redo_ctr,
+    const float* __restrict__ drop_t, int64_t ld_d, const float* __restrict__ go_prev) {
+  // drop_t (training only, SAVE): the mask of DropoutWrapper(output_keep_prob) for this step, row stride ld_d. The emitted h
+  // is h * mask, but the recurrence needs the UN-dropped h_{t-1}, and h's slot in HBM now holds the dropped one: the fill
+  // re-makes it from the saved cell state (c_prev) and the saved o gate of step t-1 (go_prev, row stride ld_g) with the very
+  // expression the previous launch evaluated — bit-identical, no second copy of h.
   // c_prev and h_out may be the SAME addresses (the cell state parked in h's next slot): no __restrict__ on them;
   // a lane reads its c before it stores its h.
   constexpr float kL2E = 1.44269504088896340736f;
@@ -101,13 +106,24 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
   // fill mapping: 32 threads per row (float4 each), 8 rows per pass
   const int fr = tid >> 5, fc4 = (tid & 31) * 4;
   RangeTrack xr = range_init();   // range of what this thread moved into the images of the current tile (f16_split.h, RANGE)
+  auto h_from_state = [&](float cv, float gv) {   // tanh(c) * o, as the gate math below forms it
+    return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(cv * (2.f * kL2E))), 1.f) * gv;
+  };
   auto fill_half = [&](const float* src, int64_t ld, int64_t row0, int rows_valid, int kbase, auto is_h) {
     float4 v[kRows / 8];
 #pragma unroll
     for (int p = 0; p < kRows / 8; ++p) {
       const int r = p * 8 + fr;
       v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < rows_valid) v[p] = *reinterpret_cast<const float4*>(src + (row0 + r) * ld + fc4);
+      if (r < rows_valid) {
+        if (decltype(is_h)::value && drop_t) {
+          const float4 cv = *reinterpret_cast<const float4*>(c_prev + (row0 + r) * ld_cp + fc4);
+          const float4 gv = *reinterpret_cast<const float4*>(go_prev + (row0 + r) * ld_g + fc4);
+          v[p] = make_float4(h_from_state(cv.x, gv.x), h_from_state(cv.y, gv.y), h_from_state(cv.z, gv.z), h_from_state(cv.w, gv.w));
+        } else {
+          v[p] = *reinterpret_cast<const float4*>(src + (row0 + r) * ld + fc4);
+        }
+      }
     }
 #pragma unroll
     for (int p = 0; p < kRows / 8; ++p) {
@@ -176,7 +192,9 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
       }
       if (live) {
         const int64_t grow = row0 + row;
-        *reinterpret_cast<f32x2*>(h_out + grow * ld_h + hid) = hn;
+        f32x2 hv = hn;
+        if (drop_t) hv *= *reinterpret_cast<const f32x2*>(drop_t + grow * ld_d + hid);
+        *reinterpret_cast<f32x2*>(h_out + grow * ld_h + hid) = hv;
         if (c_out) *reinterpret_cast<f32x2*>(c_out + grow * ld_c + hid) = cn;
         if (SAVE) {
           float* g = gates_out + grow * ld_g + hid;
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
           }
           if (!FIRST)
             for (int k = 0; k < D; ++k) {
-              const float hv = h_prev[grow * ld_hp + k];
+              const float hv = drop_t ? h_from_state(c_prev[grow * ld_cp + k], go_prev[grow * ld_g + k]) : h_prev[grow * ld_hp + k];
 #pragma unroll
               for (int g = 0; g < 4; ++g) a[g] = fmaf(hv, W[(size_t)(D + k) * NC + g * D + hid + e], a[g]);
             }
@@ -221,7 +239,9 @@ __global__ __launch_bounds__(256, 2) void lstm_step128_kernel(
           cn[e] = fmaf(cps[bt][e], act[2][e], act[0][e] * act[1][e]);
           hn[e] = tanhf(cn[e]) * act[3][e];
         }
-        *reinterpret_cast<f32x2*>(h_out + grow * ld_h + hid) = hn;
+        f32x2 hv2 = hn;
+        if (drop_t) hv2 *= *reinterpret_cast<const f32x2*>(drop_t + grow * ld_d + hid);
+        *reinterpret_cast<f32x2*>(h_out + grow * ld_h + hid) = hv2;
         if (c_out) *reinterpret_cast<f32x2*>(c_out + grow * ld_c + hid) = cn;
         if (SAVE) {
           float* g = gates_out + grow * ld_g + hid;
@@ -244,23 +264,27 @@ bool lstm_split128_supported(int d) { return d == 128; }
 template <bool SAVE, bool FIRST>
 static int launch_step(const float* x_t, int64_t ld_x, const float* h_prev, int64_t ld_hp, const float* c_prev,
                        int64_t ld_cp, const float* W, const float* b, float forget_bias, float* h_out, int64_t ld_h,
-                       float* c_out, int64_t ld_c, float* gates_out, int64_t ld_g, int64_t n, hipStream_t s) {
+                       float* c_out, int64_t ld_c, float* gates_out, int64_t ld_g, int64_t n, const float* drop_t, int64_t ld_d,
+                       const float* go_prev, hipStream_t s) {
   const size_t lds = (size_t)2 * PLANE + 16;   // 64 KB + flags: two workgroups per CU
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_step128_kernel<SAVE, FIRST>), lds)) return rc;
   const int64_t n_tiles = (n + kRows - 1) / kRows;
   const int64_t per_slice = cu_count_current() / 2 > 0 ? cu_count_current() / 2 : 1;   // 4 hidden slices share 2 workgroup slots per CU
   const int64_t bx = n_tiles < per_slice ? n_tiles : per_slice;
   hipLaunchKernelGGL((lstm_step128_kernel<SAVE, FIRST>), dim3((unsigned)bx, 4), dim3(256), lds, s, x_t, ld_x, h_prev,
-                     ld_hp, c_prev, ld_cp, W, b, forget_bias, h_out, ld_h, c_out, ld_c, gates_out, ld_g, n, n_tiles, redo_counter());
+                     ld_hp, c_prev, ld_cp, W, b, forget_bias, h_out, ld_h, c_out, ld_c, gates_out, ld_g, n, n_tiles, redo_counter(), drop_t, ld_d,
+                     go_prev);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
 
-// Same contract as lstm_fwd_mfma (drop must be NULL; d = 128). h [n, t, d] with row stride ld_h >= t*d.
+// Same contract as lstm_fwd_mfma at d = 128. h [n, t, d] with row stride ld_h >= t*d. drop [n, t, d] (dense) is taken only
+// by the training form (gates_out / c_out given: the un-dropped h_{t-1} is re-made from them).
 int lstm_fwd_split128(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, const float* W, const float* b,
-                      float forget_bias, float* h, int64_t ld_h, float* gates_out, float* c_out, const float* h_init,
-                      int64_t ld_hi, const float* c_init, float* c_final, hipStream_t s) {
+                      float forget_bias, const float* drop, float* h, int64_t ld_h, float* gates_out, float* c_out,
+                      const float* h_init, int64_t ld_hi, const float* c_init, float* c_final, hipStream_t s) {
   const bool save = gates_out != nullptr;
+  if (drop && !save) return fail(SAGNN_ERR_ARG, "d = 128 LSTM: an output-dropout mask needs the training form (saved gates / cell)");
   if (n <= 0) return SAGNN_OK;
   ProfileScope prof(kProfLstm, s, n, t);
   for (int ts = 0; ts < t; ++ts) {
@@ -290,7 +314,9 @@ int lstm_fwd_split128(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int
     float* g_t = save ? gates_out + (int64_t)ts * NC : nullptr;
     int rc;
 #define SAGNN_GO(SV, FI) \
-  rc = launch_step<SV, FI>(x_t, ld_n, h_prev, ld_hp, c_prev, ld_cp, W, b, forget_bias, h_t, ld_h, c_dst, ld_c, g_t, (int64_t)t * NC, n, s)
+  rc = launch_step<SV, FI>(x_t, ld_n, h_prev, ld_hp, c_prev, ld_cp, W, b, forget_bias, h_t, ld_h, c_dst, ld_c, g_t, (int64_t)t * NC, n, \
+                           drop ? drop + (int64_t)ts * D : nullptr, (int64_t)t * D,                                                 \
+                           (drop && ts > 0) ? gates_out + (int64_t)(ts - 1) * NC + 3 * D : nullptr, s)
     if (save && first) SAGNN_GO(true, true);
     else if (save) SAGNN_GO(true, false);
     else if (first) SAGNN_GO(false, true);

@@ -154,3 +154,34 @@ def test_a_rows_result_does_not_depend_on_its_position_in_a_tile(dev, d, t):
         h2 = ops.lstm_fwd(x[off:].contiguous(), p["lstm_W"], p["lstm_b"])
         assert torch.equal(h2, h[off:]), f"LSTM rows move with the tile offset {off}"
         assert torch.equal(att(h2), f[off:]), f"attention rows move with the tile offset {off}"
+
+
+@pytest.mark.parametrize("d,t,n", [(128, 6, 3_001), (128, 3, 70_001)])
+def test_training_lstm_with_an_output_dropout_mask(dev, d, t, n):
+    """sagnn_lstm_fwd_train_f32 with drop_scale (DropoutWrapper(output_keep_prob), model.py:137-140): the emitted h is
+    h * mask, the recurrence runs on the un-dropped h. At d = 128 the recurrence travels through HBM (one launch per step),
+    where h's slot now holds the dropped value: the next launch re-makes the un-dropped h_{t-1} from the saved cell state and
+    o gate — the gates and cell states must be bit-identical to the call without a mask, on the matrix-core kernels."""
+    from sa_gnn_amd import ops
+    lib = ops._lib.load()
+    rng = np.random.default_rng(d + t)
+    x = torch.from_numpy(rng.standard_normal((n, t, d)).astype(np.float32)).to(dev)
+    p = O.init_fusion_params(d, rng)
+    W, b = torch.from_numpy(p["lstm_W"]).to(dev), torch.from_numpy(p["lstm_b"]).to(dev)
+    drop = torch.from_numpy(((rng.random((n, t, d)) < 0.6) / 0.6).astype(np.float32)).to(dev)
+    res = []
+    for mask in (None, drop):
+        h = torch.empty((n, t, d), device=dev)
+        gates = torch.empty((n, t, 4 * d), device=dev)
+        cell = torch.empty((n, t, d), device=dev)
+        ops.range_redo_count(reset=True)
+        ops.check(lib.sagnn_lstm_fwd_train_f32(x.data_ptr(), t * d, d, n, t, d, W.data_ptr(), b.data_ptr(), 1.0,
+                                               None if mask is None else mask.data_ptr(), h.data_ptr(), t * d, gates.data_ptr(),
+                                               cell.data_ptr(), ops._stream()))
+        assert ops.range_redo_count() == 0
+        res.append((h, gates, cell))
+    (h0, g0, c0), (h1, g1, c1) = res
+    assert torch.equal(g0, g1) and torch.equal(c0, c1)
+    assert torch.equal(h1, h0 * drop)
+    want = O.basic_lstm(x.cpu().numpy(), p["lstm_W"], p["lstm_b"], 1.0)
+    np.testing.assert_allclose(h0.cpu().numpy(), want, rtol=1e-4, atol=2e-5)
