@@ -166,10 +166,9 @@ def main():
     split = isinstance(sh, SplitIntervalSharding) or frac     # T < world: ranks split an interval's target rows
     if split and a.exchange != "alltoall":
         raise SystemExit("T < world runs the all-to-all exchange only")
-    if split and a.stages == "train":
-        raise SystemExit("--stages train with T < world: the backward of the row-split stack is not built (it needs the adjoint "
-                         "of every member's row-slice SpMM — a column-sliced transposed plan per member — and a reduce-scatter "
-                         "of the partial source gradients inside each interval's group per layer); T >= world trains")
+    if split and not frac and a.stages == "train":
+        raise SystemExit("--stages train with T < world needs --split fractional (the default): the row-slice stack of the "
+                         "whole-rank groups has no backward")
     tuning = tuple(int(v) for v in a.tuning.split(",")) if a.tuning else None
     group = None
     if split:
@@ -310,13 +309,21 @@ def main():
         # (reverse all-to-all, reduce-scatter: parallel.ExchangeRowsFn / GatherFusedFn), every rank's loss is the
         # sum of ITS rows of the fused embeddings (the total is the N = 1 loss), the replicated fusion weights'
         # gradients are all-reduced, each rank steps its own intervals' embeddings.
-        if split or t_loc == 0:
-            raise SystemExit("--stages train needs at least one whole interval per rank")
+        if (split and not frac) or t_loc == 0:
+            raise SystemExit("--stages train needs at least one interval (or row stretch) per rank")
         from sa_gnn_amd import autograd as ag
         from sa_gnn_amd.parallel import allreduce_grads, exchange_rows, gather_rows
-        leaves = {"uEmbed": torch.stack([e[0] for e in emb]).requires_grad_(True),      # [T_local, U, d] / [T_local, I, d]
-                  "iEmbed": torch.stack([e[1] for e in emb]).requires_grad_(True)}
-        emb.clear()
+        if frac:      # T < world: the tables of every interval the rank meets, replicated inside the interval's group
+            leaves = {}
+            for j, k in enumerate(sh.local_intervals):
+                leaves[f"uEmbed{k}"] = emb[j][0].requires_grad_(True)
+                leaves[f"iEmbed{k}"] = emb[j][1].requires_grad_(True)
+            emb_names = [n_ for n_ in leaves]
+        else:
+            leaves = {"uEmbed": torch.stack([e[0] for e in emb]).requires_grad_(True),      # [T_local, U, d] / [T_local, I, d]
+                      "iEmbed": torch.stack([e[1] for e in emb]).requires_grad_(True)}
+            emb_names = ["uEmbed", "iEmbed"]
+            emb.clear()
         torch.cuda.empty_cache()
         shared = []
         for tag, p in (("U", prm[0]), ("I", prm[1])):
@@ -325,13 +332,18 @@ def main():
                     continue                              # the cell is shared: one leaf
                 leaves[f"{tag}.{k}"] = v.requires_grad_(True)
                 shared.append(v)
-        opt = ops.Adam(leaves, lr=1e-3, decay=0.96, decay_step=19, reg=1e-2, reg_names=["uEmbed", "iEmbed"])
+        opt = ops.Adam(leaves, lr=1e-3, decay=0.96, decay_step=19, reg=1e-2, reg_names=emb_names)
+        if frac:
+            from sa_gnn_amd.parallel import FractionalStackFn
         pl_u, pl_i = [pp[0] for pp in plans], [pp[1] for pp in plans]
 
         def step():                                       # noqa: F811  (training step replaces the forward step)
             for v in leaves.values():
                 v.grad = None
-            if use_batch:
+            if frac:      # the rank's row slices of every interval it meets; the adjoint all-gathers the table gradients per group
+                us, its = FractionalStackFn.apply(runner, ops.spmm_ex, ops.mask_scale, frac_plans, L, 0.5,
+                                                  *[leaves[n_] for n_ in emb_names])
+            elif use_batch:
                 us, its = ag.gnn_stack(leaves["uEmbed"], leaves["iEmbed"], batch, None, L, 0.5)
             else:
                 us, its = ag.gnn_stack(leaves["uEmbed"], leaves["iEmbed"], pl_u, pl_i, L, 0.5)  # [T_local, N, d] slabs, no stack copy

@@ -180,6 +180,10 @@ typedef struct sagnn_spmm_epilogue {
 int sagnn_spmm_ex_f32(const sagnn_spmm_plan* plan, const float* X, int64_t ldx, int d,
                       const sagnn_spmm_epilogue* epilogue, void* workspace, size_t workspace_bytes,
                       void* stream);
+/* out[r, :] = g[r, :] * (mask bit ? 1 : slope), mask [n_rows, d/4] bytes as sagnn_spmm_ex_f32 records them: the seed of the
+ * backward chain of the interval stack, for hosts that run the chain on row slices themselves (T < world sharding). */
+int sagnn_mask_scale_f32(const float* g, int64_t ldg, const uint8_t* mask, float slope, float* out, int64_t ldo,
+                         int64_t n_rows, int d, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * sagnn_gnn_interval_f32 — one iteration k of the loop model.py:118-129 (L layers, both

@@ -58,6 +58,7 @@ SIGNATURES = {
                                c_size_t, c_void_p]),
     "sagnn_spmm_ex_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, POINTER(SpmmEpilogue), c_void_p, c_size_t,
                                   c_void_p]),
+    "sagnn_mask_scale_f32": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "sagnn_gnn_interval_ex_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int,
                                           c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

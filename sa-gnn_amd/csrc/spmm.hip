@@ -725,6 +725,23 @@ extern "C" int sagnn_spmm_f32(const sagnn_spmm_plan* plan, const float* X, int64
   return sagnn_spmm_ex_f32(plan, X, ldx, d, &e, workspace, workspace_bytes, stream);
 }
 
+// out[r, :] = g[r, :] * (mask bit ? 1 : slope): the seed of the backward chain (what sagnn_gnn_interval_bwd_f32 does first),
+// exposed for hosts that run the chain themselves on row slices (parallel.FractionalRunner.run_backward).
+extern "C" int sagnn_mask_scale_f32(const float* g, int64_t ldg, const uint8_t* mask, float slope, float* out, int64_t ldo,
+                                    int64_t n_rows, int d, void* stream) {
+  if (!g || !mask || !out) return sagnn::fail(SAGNN_ERR_NULL, "null pointer");
+  if (d < 4 || d > 256 || (d & 3)) return sagnn::fail(SAGNN_ERR_DIM, "d = %d: need a multiple of 4 in [4, 256]", d);
+  if (n_rows < 0) return sagnn::fail(SAGNN_ERR_ARG, "n_rows = %lld", (long long)n_rows);
+  if (int rc = check_mat("g", g, ldg, d, true)) return rc;
+  if (int rc = check_mat("out", out, ldo, d, true)) return rc;
+  const int64_t n = n_rows * (d / 4);
+  if (n == 0) return SAGNN_OK;
+  hipLaunchKernelGGL(mask_scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), g, ldg,
+                     mask, d / 4, slope, out, ldo, n_rows, d);
+  SAGNN_HIP_TRY(hipGetLastError());
+  return SAGNN_OK;
+}
+
 namespace {
 int check_interval_plans(const sagnn_spmm_plan* pu, const sagnn_spmm_plan* pi) {
   if (!pu || !pi) return sagnn::fail(SAGNN_ERR_NULL, "plan is NULL");

@@ -178,6 +178,43 @@ def spmm(plan: SpmmPlan, x: torch.Tensor, leaky: float, residual: torch.Tensor |
     return out
 
 
+def spmm_ex(plan: SpmmPlan, x: torch.Tensor | None, leaky: float, residual=None, out=None, acc_in=None, acc_out=None,
+            acc_in2=None, mask_out=None, mask_in=None, out2=None, slope2: float = 1.0, want_out: bool = False):
+    """sagnn_spmm_ex_f32: spmm plus the training epilogue — mask_out [rows, d/4] uint8 records the activation slopes,
+    out2 = v * (mask_in bit ? 1 : slope2) with v the accumulated value if acc_out is given, acc_in2 a second addend."""
+    ref = next(t_ for t_ in (x, residual, out, acc_out, out2) if t_ is not None)
+    d = int(ref.shape[1])
+    if out is None and want_out:
+        out = torch.empty((plan.n_rows, d), dtype=torch.float32, device=ref.device)
+    e = _lib.SpmmEpilogue()
+    e.leaky, e.slope2 = float(leaky), float(slope2)
+    e.residual, e.ldr = _ptr(residual), _f32_rows("residual", residual, d, plan.n_rows)
+    e.out, e.ldo = _ptr(out), _f32_rows("out", out, d, plan.n_rows)
+    e.acc_in, e.ld_acc_in = _ptr(acc_in), _f32_rows("acc_in", acc_in, d, plan.n_rows)
+    e.acc_out, e.ld_acc_out = _ptr(acc_out), _f32_rows("acc_out", acc_out, d, plan.n_rows)
+    e.acc_in2, e.ld_acc_in2 = _ptr(acc_in2), _f32_rows("acc_in2", acc_in2, d, plan.n_rows)
+    e.out2, e.ldo2 = _ptr(out2), _f32_rows("out2", out2, d, plan.n_rows)
+    for name, m in (("mask_out", mask_out), ("mask_in", mask_in)):
+        if m is not None and (m.dtype != torch.uint8 or not m.is_contiguous() or m.numel() != plan.n_rows * (d // 4)):
+            raise ValueError(f"{name}: need a contiguous uint8 tensor [{plan.n_rows}, {d // 4}]")
+    e.mask_out, e.mask_in = _ptr(mask_out), _ptr(mask_in)
+    ldx = _f32_rows("x", x, d, plan.n_src) if x is not None else d
+    ws = plan.workspace(d)
+    check(plan._lib.sagnn_spmm_ex_f32(plan.handle, _ptr(x), ldx, d, ctypes.byref(e), _ptr(ws), 0 if ws is None else ws.numel() * 4,
+                                      _stream()))
+    return out
+
+
+def mask_scale(g: torch.Tensor, mask: torch.Tensor, slope: float, out: torch.Tensor):
+    """out = g * (mask bit ? 1 : slope) (sagnn_mask_scale_f32); g / out [rows, d] views, mask [rows, d/4] uint8."""
+    rows, d = int(g.shape[0]), int(g.shape[1])
+    if mask.dtype != torch.uint8 or not mask.is_contiguous() or mask.numel() != rows * (d // 4):
+        raise ValueError(f"mask: need a contiguous uint8 tensor [{rows}, {d // 4}]")
+    check(_lib.load().sagnn_mask_scale_f32(_ptr(g), _f32_rows("g", g, d, rows), _ptr(mask), float(slope), _ptr(out),
+                                           _f32_rows("out", out, d, rows), rows, d, _stream()))
+    return out
+
+
 def _interval_ws(plan_user: SpmmPlan, plan_item: SpmmPlan, d: int):
     wu, wi = plan_user.workspace(d), plan_item.workspace(d)
     return wu if (wi is None or (wu is not None and wu.numel() >= wi.numel())) else wi

@@ -277,15 +277,20 @@ class FractionalRunner:
         self.out_u = torch.empty((sum(hi - lo for lo, hi in self.ru.values()), d), dtype=dtype, device=device)
         self.out_i = torch.empty((sum(hi - lo for lo, hi in self.ri.values()), d), dtype=dtype, device=device)
 
-    def run(self, spmm, plans: dict, emb: dict, n_layers: int, leaky: float):
-        """emb[k] = (u0 [U, d], i0 [I, d]) of every interval this rank meets."""
-        sh = self.sh
-        ou, oi = 0, 0
-        acc = {}
-        for k in self.ks:                       # the rank's slices of the running sums, views into the send buffers
+    def _views(self, buf_u, buf_i):
+        ou, oi, v = 0, 0, {}
+        for k in self.ks:
             (lu, hu), (li, hi) = self.ru[k], self.ri[k]
-            acc[k] = (self.out_u[ou: ou + hu - lu], self.out_i[oi: oi + hi - li])
+            v[k] = (buf_u[ou: ou + hu - lu], buf_i[oi: oi + hi - li])
             ou, oi = ou + hu - lu, oi + hi - li
+        return v
+
+    def run(self, spmm, plans: dict, emb: dict, n_layers: int, leaky: float, masks: dict | None = None):
+        """emb[k] = (u0 [U, d], i0 [I, d]) of every interval this rank meets. masks[k] = (mask_u [L, rows_u, d/4],
+        mask_i [L, rows_i, d/4]) uint8: record the activation slopes of this rank's rows (training; spmm must then take
+        the extended epilogue, ops.spmm_ex)."""
+        sh = self.sh
+        acc = self._views(self.out_u, self.out_i)     # the rank's slices of the running sums, views into the send buffers
         cur = {k: emb[k] for k in self.ks}
         for l in range(n_layers):
             last = l + 1 == n_layers
@@ -293,11 +298,12 @@ class FractionalRunner:
                 (lu, hu), (li, hi) = self.ru[k], self.ri[k]
                 cu, ci = cur[k]
                 nu, ni = self.tab_u[k][l & 1], self.tab_i[k][l & 1]
-                for plan, src, c, lo, hi_, nxt, a in ((plans[k][0], ci, cu, lu, hu, nu, acc[k][0]),
-                                                      (plans[k][1], cu, ci, li, hi, ni, acc[k][1])):
+                for side, (plan, src, c, lo, hi_, nxt, a) in enumerate(((plans[k][0], ci, cu, lu, hu, nu, acc[k][0]),
+                                                                        (plans[k][1], cu, ci, li, hi, ni, acc[k][1]))):
                     if hi_ > lo:
+                        kw = {} if masks is None else {"mask_out": masks[k][side][l]}
                         spmm(plan, src[: plan.n_src], leaky, residual=c[lo:hi_], out=None if last else nxt[lo:hi_],
-                             acc_in=c[lo:hi_] if l == 0 else a, acc_out=a, want_out=not last)
+                             acc_in=c[lo:hi_] if l == 0 else a, acc_out=a, want_out=not last, **kw)
             if last:
                 break
             for k in self.ks:                    # ascending k on every rank: no cycle between overlapping groups
@@ -306,6 +312,83 @@ class FractionalRunner:
                 _all_gather_rows(self.tab_i[k][l & 1], sh.cuts(self.I, k), m, self.groups[k], self.comm_device)
                 cur[k] = (self.tab_u[k][l & 1], self.tab_i[k][l & 1])
         return self.out_u, self.out_i
+
+    def run_backward(self, spmm, mask_scale, plans: dict, G_u: torch.Tensor, G_i: torch.Tensor, masks: dict, n_layers: int,
+                     leaky: float):
+        """Backward of run(): G_u / G_i = dL/d(out_u), dL/d(out_i) (the rank's slices, interval order) -> {k: (dL/d u0
+        [U, d], dL/d i0 [I, d])} FULL tables, the same on every member of interval k's group. The recurrence of
+        sagnn_gnn_interval_bwd_f32 on row slices:  g^l[slice] = G + g^{l+1}[slice] + A[slice, :] (g_partner^{l+1} * m^{l+1}),
+        where the masked partner gradient is a FULL table: every member makes its slice of it (the epilogue's out2) and
+        the group all-gathers it — exactly the forward's pattern, on the forward's own row-slice plans (matrices without
+        duplicated stored entries: the user-side pattern is the adjoint of the item-side one)."""
+        sh, d = self.sh, self.d
+        Gv = self._views(G_u, G_i)
+        dev, dt = G_u.device, G_u.dtype
+        gfull = {k: tuple(torch.empty((2,) + tuple(g.shape), dtype=dt, device=dev) for g in Gv[k]) for k in self.ks}
+        out = {}
+        for k in self.ks:                        # seed: (G * m^L) of my rows into the full tables, then the group's
+            (lu, hu), (li, hi) = self.ru[k], self.ri[k]
+            if hu > lu:
+                mask_scale(Gv[k][0], masks[k][0][n_layers - 1], leaky, self.tab_u[k][0][lu:hu])
+            if hi > li:
+                mask_scale(Gv[k][1], masks[k][1][n_layers - 1], leaky, self.tab_i[k][0][li:hi])
+        cur = 0
+        gnext = {k: Gv[k] for k in self.ks}      # g^{l+1} slices
+        for l in range(n_layers - 1, -1, -1):
+            for k in self.ks:
+                m = sh.members(k).index(sh.rank)
+                _all_gather_rows(self.tab_u[k][cur], sh.cuts(self.U, k), m, self.groups[k], self.comm_device)
+                _all_gather_rows(self.tab_i[k][cur], sh.cuts(self.I, k), m, self.groups[k], self.comm_device)
+            final = l == 0
+            for k in self.ks:
+                (lu, hu), (li, hi) = self.ru[k], self.ri[k]
+                if final:
+                    out[k] = (torch.zeros((self.U, d), dtype=dt, device=dev), torch.zeros((self.I, d), dtype=dt, device=dev))
+                for side, (plan, src, lo, hi_) in enumerate(((plans[k][0], self.tab_i[k][cur], lu, hu),
+                                                             (plans[k][1], self.tab_u[k][cur], li, hi))):
+                    if hi_ <= lo:
+                        continue
+                    dst = out[k][side][lo:hi_] if final else gfull[k][side][l & 1]
+                    kw = {}
+                    if not final:
+                        tab = (self.tab_u if side == 0 else self.tab_i)[k][cur ^ 1]
+                        kw = {"mask_in": masks[k][side][l - 1], "out2": tab[lo:hi_], "slope2": leaky}
+                    spmm(plan, src[: plan.n_src], 1.0, residual=gnext[k][side], acc_in=Gv[k][side], acc_out=dst, want_out=False, **kw)
+                if not final:
+                    gnext[k] = (gfull[k][0][l & 1], gfull[k][1][l & 1])
+            cur ^= 1
+        for k in self.ks:                        # every member ends with the whole gradient of the replicated tables
+            m = sh.members(k).index(sh.rank)
+            _all_gather_rows(out[k][0], sh.cuts(self.U, k), m, self.groups[k], self.comm_device)
+            _all_gather_rows(out[k][1], sh.cuts(self.I, k), m, self.groups[k], self.comm_device)
+        return out
+
+
+class FractionalStackFn(torch.autograd.Function):
+    """FractionalRunner.run with its adjoint: (u0, i0 of every interval the rank meets; replicated inside an interval's
+    group) -> (out_u, out_i) = the rank's row slices of sum_l e^l. Backward returns the WHOLE gradient of every table
+    (all-gathered inside the group), so that every member applies the same optimiser step to its replica."""
+
+    @staticmethod
+    def forward(ctx, runner, spmm, mask_scale, plans, n_layers, leaky, *embs):
+        ks = runner.ks
+        emb = {k: (embs[2 * j].detach(), embs[2 * j + 1].detach()) for j, k in enumerate(ks)}
+        d, dev = runner.d, embs[0].device
+        masks = {k: (torch.empty((n_layers, runner.ru[k][1] - runner.ru[k][0], d // 4), dtype=torch.uint8, device=dev),
+                     torch.empty((n_layers, runner.ri[k][1] - runner.ri[k][0], d // 4), dtype=torch.uint8, device=dev)) for k in ks}
+        ou, oi = runner.run(spmm, plans, emb, n_layers, leaky, masks=masks)
+        ctx.runner, ctx.spmm, ctx.mask_scale, ctx.plans, ctx.cfg, ctx.masks = runner, spmm, mask_scale, plans, (n_layers, leaky), masks
+        return ou.clone(), oi.clone()
+
+    @staticmethod
+    def backward(ctx, g_u, g_i):
+        n_layers, leaky = ctx.cfg
+        grads = ctx.runner.run_backward(ctx.spmm, ctx.mask_scale, ctx.plans, g_u.contiguous(), g_i.contiguous(), ctx.masks, n_layers,
+                                        leaky)
+        flat = []
+        for k in ctx.runner.ks:
+            flat += [grads[k][0], grads[k][1]]
+        return (None, None, None, None, None, None) + tuple(flat)
 
 
 def csr_row_slice(rowptr, colidx, lo: int, hi: int):
@@ -654,14 +737,12 @@ class GatherFusedFn(torch.autograd.Function):
 
 
 class ExchangeRowsFn(torch.autograd.Function):
-    """exchange_to_row_shards(mode="alltoall") with its adjoint: forward [T_local, N, d] -> x [T, rows_local, d];
-    backward sends every interval's gradient rows back to the interval's owner (the same all-to-all with send and
-    receive swapped), which reassembles dL/d(out_k) [N, d] for its local intervals."""
+    """exchange_to_row_shards(mode="alltoall") with its adjoint: forward [T_local, N, d] (T >= world) or the rank's row
+    slices [rows, d] (T < world) -> x [T, rows_local, d]; backward sends every gradient row back to where its value came
+    from (the same all-to-all with send and receive swapped)."""
 
     @staticmethod
     def forward(ctx, local_out, sh, n_rows, group):
-        if isinstance(sh, (SplitIntervalSharding, FractionalSharding)):
-            raise NotImplementedError("backward of the row-split exchange (T < world) is not built")
         ctx.sh, ctx.n_rows, ctx.group, ctx.t_loc = sh, n_rows, group, local_out.shape[0]
         return exchange_to_row_shards(local_out.detach().contiguous(), sh, n_rows, group, mode="alltoall")
 
@@ -674,6 +755,19 @@ class ExchangeRowsFn(torch.autograd.Function):
         g = g.contiguous()
         bounds = sh.row_bounds(n_rows)
         rows_local = bounds[sh.rank + 1] - bounds[sh.rank]
+        if isinstance(sh, (SplitIntervalSharding, FractionalSharding)):
+            ins, outs = sh.exchange_splits(n_rows)               # forward: sent `ins`, received `outs`
+            back = g.new_empty((sum(ins), d))                    # arrives in SEND order (grouped by the shard it went to)
+            dist.all_to_all_single(back, g.view(sh.T * rows_local, d), output_split_sizes=ins, input_split_sizes=outs,
+                                   group=ctx.group)
+            if isinstance(sh, FractionalSharding) and len(sh.intervals_of(sh.rank)) > 1:
+                d_rows = torch.empty_like(back)
+                pos = 0
+                for off, n in sh.send_order(n_rows):             # undo the send permutation
+                    d_rows[off:off + n] = back[pos:pos + n]
+                    pos += n
+                back = d_rows
+            return back, None, None, None
         d_local = g.new_empty((ctx.t_loc, n_rows, d))
         shard_sizes = [bounds[r + 1] - bounds[r] for r in range(sh.world)]
         for j in range(sh.rounds):

@@ -382,3 +382,108 @@ def test_fractional_sharding_maps_balance_edges():
     grp = [SplitIntervalSharding(5, 8, r, w) for r in range(8)]
     load_g = [(g.slice_range(U)[1] - g.slice_range(U)[0]) / U * w[g.interval] for g in grp]
     assert max(load_g) >= 1.6 * sum(w) / 8
+
+
+# ---- training with fewer intervals than ranks: the row-slice stack and the one all-to-all carry their adjoints
+def _bits(slopes_one):
+    """[rows, d] bool (True = slope 1) -> [rows, d/4] uint8, bit j of byte l = column 4 l + j (sagnn_spmm_ex_f32's layout)."""
+    b = slopes_one.reshape(slopes_one.shape[0], -1, 4).to(torch.uint8)
+    return (b[..., 0] | (b[..., 1] << 1) | (b[..., 2] << 2) | (b[..., 3] << 3)).contiguous()
+
+
+def _unbits(mask, d):
+    m = mask.to(torch.int32)
+    return torch.stack([(m >> j) & 1 for j in range(4)], dim=-1).reshape(mask.shape[0], d).bool()
+
+
+def _cpu_spmm_ex(plan, x, leaky, residual=None, out=None, acc_in=None, acc_out=None, want_out=True, acc_in2=None,
+                 mask_out=None, mask_in=None, out2=None, slope2=1.0):
+    """ops.spmm_ex's contract on the CPU (sagnn_spmm_ex_f32's epilogue, finish_row in csrc/spmm.hip)."""
+    s = torch.from_numpy(plan.mat @ x.numpy())
+    y = torch.maximum(leaky * s, s)
+    if mask_out is not None:
+        mask_out.copy_(_bits(s > leaky * s))
+    if residual is not None:
+        y = y + residual
+    if out is not None:
+        out.copy_(y)
+    v = y
+    if acc_out is not None:
+        v = y + (acc_in if acc_in is not None else 0) + (acc_in2 if acc_in2 is not None else 0)
+        acc_out.copy_(v)
+    if out2 is not None:
+        keep = _unbits(mask_in, v.shape[1]) if mask_in is not None else torch.ones_like(v, dtype=torch.bool)
+        out2.copy_(torch.where(keep, v, slope2 * v))
+    return out
+
+
+def _cpu_mask_scale(g, mask, slope, out):
+    out.copy_(torch.where(_unbits(mask, g.shape[1]), g, slope * g))
+    return out
+
+
+def _frac_train_worker(rank, world, port, T, weights, q):
+    from sa_gnn_amd.graph import csr_arrays, transpose
+    from sa_gnn_amd.parallel import FractionalRunner, FractionalStackFn, csr_row_slice, exchange_rows, make_sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        U, I, d, L = 23, 17, 16, 3
+        mats, ue, ie, _ = _problem(T, U, I, d)
+        rng = np.random.default_rng(5)
+        w_u, w_i = rng.standard_normal((T, U, d)).astype(np.float32), rng.standard_normal((T, I, d)).astype(np.float32)
+        sh = make_sharding(T, world, rank, weights)
+        groups = [dist.new_group(sh.members(k)) for k in range(T)]
+        plans, leaves = {}, []
+        for k in sh.intervals_of(rank):
+            rp_u, ci_u = csr_arrays(mats[k])
+            rp_i, ci_i = csr_arrays(transpose(mats[k]))
+            (lu, hu), (li, hi) = sh.slice_range(U, k), sh.slice_range(I, k)
+            plans[k] = (_CpuPlan(*csr_row_slice(rp_u, ci_u, lu, hu), hu - lu, I), _CpuPlan(*csr_row_slice(rp_i, ci_i, li, hi), hi - li, U))
+            leaves += [torch.from_numpy(ue[k]).requires_grad_(True), torch.from_numpy(ie[k]).requires_grad_(True)]
+        run = FractionalRunner(sh, U, I, d, torch.device("cpu"), {k: groups[k] for k in sh.intervals_of(rank)})
+        ou, oi = FractionalStackFn.apply(run, _cpu_spmm_ex, _cpu_mask_scale, plans, L, 0.5, *leaves)
+        loss = 0.0
+        for o_, n_rows, w in ((ou, U, w_u), (oi, I, w_i)):
+            x = exchange_rows(o_, sh, n_rows)                               # [T, rows_local, d]
+            lo, hi_ = sh.row_range(n_rows)
+            loss = loss + (x * torch.from_numpy(w[:, lo:hi_])).sum()        # this rank's rows of the total loss
+        loss.backward()
+        q.put((rank, sh.intervals_of(rank), [t.grad.numpy() for t in leaves], float(loss)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T,weights", [(8, 5, [72280, 78997, 79692, 78096, 45651]), (4, 3, None), (3, 2, [3, 1])])
+def test_fractional_training_gradients_match_single_process(world, T, weights):
+    """Forward + backward of the T < world pipeline up to the exchange: the row-slice stack records its activation masks,
+    the backward runs the same row-slice SpMMs on all-gathered masked gradient tables, the all-to-all runs in reverse
+    (undoing the send permutation of two-segment ranks), and every member of an interval's group ends with the WHOLE
+    gradient of the interval's embedding tables. Against float64 autograd of the single-process loss."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_frac_train_worker, args=(r, world, port, T, weights, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p_ in procs:
+        p_.join(60)
+        assert p_.exitcode == 0
+    U, I, d, L = 23, 17, 16, 3
+    mats, ue, ie, _ = _problem(T, U, I, d)
+    rng = np.random.default_rng(5)
+    w_u, w_i = rng.standard_normal((T, U, d)).astype(np.float32), rng.standard_normal((T, I, d)).astype(np.float32)
+    tu = torch.tensor(ue, dtype=torch.float64, requires_grad=True)
+    ti = torch.tensor(ie, dtype=torch.float64, requires_grad=True)
+    total = 0.0
+    for k in range(T):
+        a, b = O.torch_gnn_interval(tu[k], ti[k], O.trans_to_lsts(mats[k])[0], O.trans_to_lsts(O.transpose(mats[k]))[0], L, 0.5)
+        total = total + (a * torch.tensor(w_u[k], dtype=torch.float64)).sum() + (b * torch.tensor(w_i[k], dtype=torch.float64)).sum()
+    total.backward()
+    assert abs(sum(r[3] for r in res) - float(total)) <= 1e-4 * abs(float(total)) + 1e-3
+    for rank, ks, grads, _ in res:
+        for j, k in enumerate(ks):
+            np.testing.assert_allclose(grads[2 * j], tu.grad[k].numpy(), rtol=2e-4, atol=2e-4)
+            np.testing.assert_allclose(grads[2 * j + 1], ti.grad[k].numpy(), rtol=2e-4, atol=2e-4)
