@@ -234,27 +234,27 @@ class IntervalFusionFn(torch.autograd.Function):
             dx, dW, db = lstm_bwd(x, h, gates, cell, dh, drop, lstm_W.detach())
             return (dx, dW, db, dgamma, dbeta) + _split_qkv_grads(dWqkv, dbqkv, d) + (None, None)
         Wd = lstm_W.detach()
-        WxT = Wd[:d].t().contiguous()                                                    # [4d, d]
-        WhT = Wd[d:].t().contiguous()
+        WT = Wd.t().contiguous()                                                         # [4d, 2d]: d[x | h] = dgates W^T in ONE product
         dW = torch.zeros((2 * d, 4 * d), dtype=torch.float32, device=dev)
         db = torch.zeros(4 * d, dtype=torch.float32, device=dev)
         dx = torch.empty((n, t, d), dtype=torch.float32, device=dev)
         dgates = torch.empty((n, 4 * d), dtype=torch.float32, device=dev)
         dc = [torch.empty((n, d), dtype=torch.float32, device=dev) for _ in range(2)]
-        dh_rec = torch.empty((n, d), dtype=torch.float32, device=dev)
+        dxh = torch.empty((n, 2 * d), dtype=torch.float32, device=dev)                   # [dx_t | dh_{t-1}]
+        dh_rec = dxh[:, d:]                                                               # row stride 2d
         h_state = h                                   # un-dropped: the recurrent operand
         for ts in range(t - 1, -1, -1):
             last = ts == t - 1
             ops.check(lib.sagnn_lstm_bwd_step_f32(
                 gates.data_ptr(), cell.data_ptr(), dh.data_ptr(), t * d, ops._ptr(drop),
-                None if last else dh_rec.data_ptr(), d, None if last else dc[(ts + 1) & 1].data_ptr(),
+                None if last else dh_rec.data_ptr(), 2 * d, None if last else dc[(ts + 1) & 1].data_ptr(),
                 dgates.data_ptr(), dc[ts & 1].data_ptr(), n, t, d, ts, st))
             x_t = x[:, ts, :]
             ops.dense_tn(x_t, dgates, dW[:d], db)
             if ts > 0:
                 ops.dense_tn(h_state[:, ts - 1, :], dgates, dW[d:], None)
-                ops.dense_nn(dgates, WhT, None, out=dh_rec)
-            ops.dense_nn(dgates, WxT, None, out=dx[:, ts, :])
+            ops.dense_nn(dgates, WT, None, out=dxh)
+            dx[:, ts, :].copy_(dxh[:, :d])
         return (dx, dW, db, dgamma, dbeta) + _split_qkv_grads(dWqkv, dbqkv, d) + (None, None)
 
 

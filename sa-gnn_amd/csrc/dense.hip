@@ -352,6 +352,9 @@ namespace sagnn {
 // slices of <= 256 and row (K) chunks whose W block fits LDS; later chunks accumulate.
 int dense_nn_any(const float* X, int64_t ldx, int64_t n, int din, int dout, const float* W, int64_t ldw,
                  const float* bias, float* Y, int64_t ldy, int accumulate, hipStream_t s) {
+  // a W that does not fit LDS next to the staging tiles would be cut into pieces, every piece re-reading X: the tiled
+  // GEMM of dense_gemm.hip streams both operands instead (the d = 128 BPTT products)
+  if ((int64_t)din * dout > kLdsFloatsForW) return gemm_nn(X, ldx, n, din, dout, W, ldw, bias, Y, ldy, accumulate, s);
   for (int c0 = 0; c0 < dout; c0 += 256) {
     const int cw = dout - c0 < 256 ? dout - c0 : 256;
     int kmax = (kLdsFloatsForW / cw) / 32 * 32;
@@ -369,6 +372,7 @@ int dense_nn_any(const float* X, int64_t ldx, int64_t n, int din, int dout, cons
 // dW += X^T G, db += colsum(G) for any multiples of 32: 256 x 256 output blocks at most per launch.
 int dense_tn_any(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW,
                  int64_t lddw, float* db, hipStream_t s) {
+  if (din > 128 || dout > 256) return gemm_tn(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);   // more than one piece: dense_gemm.hip
   for (int r0 = 0; r0 < din; r0 += 128) {
     const int rw = din - r0 < 128 ? din - r0 : 128;
     for (int c0 = 0; c0 < dout; c0 += 256) {
