@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SAGNN_VERSION 10300 /* 1.3.0 */
+#define SAGNN_VERSION 10301 /* 1.3.0 */
 
 enum {
   SAGNN_OK = 0,
@@ -495,13 +495,20 @@ int sagnn_adam_multi_f32(int n_tensors, float* const* params, const float* const
  *   sagnn_dense_tn_f32:  dW[din, dout] += X[n, din]^T @ G[n, dout];  db[dout] += column sums of G
  *       (db nullable). The weight-gradient products; accumulates with float atomics, so zero
  *       dW/db first and expect run-to-run differences in the last bits.
- * din, dout: any multiples of 32; products whose W block exceeds LDS or 256 columns are cut into
- * column slices / K chunks internally (later chunks accumulate).
+ *   sagnn_dense_tn_seg_f32: the same sums over n_seg row SEGMENTS of seg_rows rows each, row i of segment s
+ *       at X + s * x_seg + i * ldx and G + s * g_seg + i * ldg (strides in floats, multiples of 4;
+ *       seg_rows * n_seg < 2^31): the weight gradient of a whole BPTT in one launch — x [n, t, d] in any
+ *       node / interval strides against the stored gate gradients [t, n, 4d] — instead of one product per step.
+ * din, dout: any multiples of 32. A W block that fits LDS stays resident there and the tall operand streams
+ * past it; larger blocks (the d = 128 LSTM: [512, 256]) and the segmented form run a tiled GEMM
+ * (dense_gemm.hip: 128 x 128 / 64 x 128 block tiles, split-K with atomics for the transposed form).
  * -------------------------------------------------------------------------------- */
 int sagnn_dense_nn_f32(const float* X, int64_t ldx, int64_t n, int din, int dout, const float* W,
                        const float* bias, float* Y, int64_t ldy, int accumulate, void* stream);
 int sagnn_dense_tn_f32(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din,
                        int dout, float* dW, float* db, void* stream);
+int sagnn_dense_tn_seg_f32(const float* X, int64_t ldx, int64_t x_seg, const float* G, int64_t ldg, int64_t g_seg,
+                           int64_t seg_rows, int n_seg, int din, int dout, float* dW, float* db, void* stream);
 
 #ifdef __cplusplus
 }

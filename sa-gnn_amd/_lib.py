@@ -130,6 +130,8 @@ SIGNATURES = {
                                    c_int, c_void_p]),
     "sagnn_dense_tn_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,
                                    c_void_p]),
+    "sagnn_dense_tn_seg_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p]),
     "sagnn_lstm_fwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p,
                                    c_float, c_void_p, c_void_p, c_int64, c_void_p]),
     "sagnn_lstm_fwd_state_f32": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p, c_float,

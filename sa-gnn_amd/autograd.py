@@ -11,6 +11,7 @@ from . import ops
 # that the fused entries (attention-backward front + tail, one-launch BPTT) replaced.
 FUSED_ATTN_BWD = True
 FUSED_BPTT = True
+DEFERRED_DW_LIMIT = 4 << 30   # bytes of gate gradients ([t, n, 4d]) the generic BPTT may keep for the one-launch weight gradient
 
 
 class GnnIntervalFn(torch.autograd.Function):
@@ -233,29 +234,34 @@ class IntervalFusionFn(torch.autograd.Function):
         if lib.sagnn_lstm_bwd_supported(d) and FUSED_BPTT:
             dx, dW, db = lstm_bwd(x, h, gates, cell, dh, drop, lstm_W.detach())
             return (dx, dW, db, dgamma, dbeta) + _split_qkv_grads(dWqkv, dbqkv, d) + (None, None)
-        Wd = lstm_W.detach()
-        WT = Wd.t().contiguous()                                                         # [4d, 2d]: d[x | h] = dgates W^T in ONE product
+        # generic BPTT (any d that is a multiple of 32; d = 128 is BASELINE config 3). Per step: the element-wise gate
+        # backward and ONE product d[x_t | h_{t-1}] = dG_t W^T written where the next step reads it. The gate gradients of
+        # all steps stay in HBM ([t, n, 4d]) and the weight gradient is two segmented products after the loop instead of
+        # 2 t small ones (each of those a split-K launch ending in 64 K float atomics per block).
+        WT = lstm_W.detach().t().contiguous()                                            # [4d, 2d]
         dW = torch.zeros((2 * d, 4 * d), dtype=torch.float32, device=dev)
         db = torch.zeros(4 * d, dtype=torch.float32, device=dev)
-        dx = torch.empty((n, t, d), dtype=torch.float32, device=dev)
-        dgates = torch.empty((n, 4 * d), dtype=torch.float32, device=dev)
+        defer = n * t * 4 * d * 4 <= DEFERRED_DW_LIMIT
+        dG = torch.empty((t if defer else 1, n, 4 * d), dtype=torch.float32, device=dev)
         dc = [torch.empty((n, d), dtype=torch.float32, device=dev) for _ in range(2)]
-        dxh = torch.empty((n, 2 * d), dtype=torch.float32, device=dev)                   # [dx_t | dh_{t-1}]
-        dh_rec = dxh[:, d:]                                                               # row stride 2d
-        h_state = h                                   # un-dropped: the recurrent operand
+        dxh = torch.empty((n, t, 2 * d), dtype=torch.float32, device=dev)                # [dx_t | dh_{t-1}] per step
         for ts in range(t - 1, -1, -1):
             last = ts == t - 1
+            dgates = dG[ts if defer else 0]
             ops.check(lib.sagnn_lstm_bwd_step_f32(
                 gates.data_ptr(), cell.data_ptr(), dh.data_ptr(), t * d, ops._ptr(drop),
-                None if last else dh_rec.data_ptr(), 2 * d, None if last else dc[(ts + 1) & 1].data_ptr(),
+                None if last else dxh[:, ts + 1, d:].data_ptr(), t * 2 * d, None if last else dc[(ts + 1) & 1].data_ptr(),
                 dgates.data_ptr(), dc[ts & 1].data_ptr(), n, t, d, ts, st))
-            x_t = x[:, ts, :]
-            ops.dense_tn(x_t, dgates, dW[:d], db)
-            if ts > 0:
-                ops.dense_tn(h_state[:, ts - 1, :], dgates, dW[d:], None)
-            ops.dense_nn(dgates, WT, None, out=dxh)
-            dx[:, ts, :].copy_(dxh[:, :d])
-        return (dx, dW, db, dgamma, dbeta) + _split_qkv_grads(dWqkv, dbqkv, d) + (None, None)
+            if not defer:
+                ops.dense_tn(x[:, ts, :], dgates, dW[:d], db)
+                if ts > 0:
+                    ops.dense_tn(h[:, ts - 1, :], dgates, dW[d:], None)                  # h un-dropped: the recurrent operand
+            ops.dense_nn(dgates, WT, None, out=dxh[:, ts, :])
+        if defer:
+            ops.dense_tn_seg(x.permute(1, 0, 2), dG, dW[:d], db)
+            if t > 1:
+                ops.dense_tn_seg(h.permute(1, 0, 2)[:t - 1], dG[1:], dW[d:], None)
+        return (dxh[:, :, :d].contiguous(), dW, db, dgamma, dbeta) + _split_qkv_grads(dWqkv, dbqkv, d) + (None, None)
 
 
 def interval_fusion(x, p: dict, heads: int, drop_scale=None):

@@ -88,8 +88,8 @@ int dense_tn_any(const float* X, int64_t ldx, const float* G, int64_t ldg, int64
 // dense_gemm.hip: tiled fp32-MFMA GEMMs for weight blocks that do not fit LDS (the d = 128 BPTT products)
 int gemm_nn(const float* X, int64_t ldx, int64_t n, int din, int dout, const float* W, int64_t ldw, const float* bias, float* Y,
             int64_t ldy, int accumulate, hipStream_t s);
-int gemm_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW, int64_t lddw, float* db,
-            hipStream_t s);
+int gemm_tn(const float* X, int64_t ldx, int64_t xseg, const float* G, int64_t ldg, int64_t gseg, int64_t seg_rows, int64_t n_seg,
+            int din, int dout, float* dW, int64_t lddw, float* db, hipStream_t s);
 bool force_valu();  // the calling thread chose SAGNN_ENGINE_VALU
 
 // ---- optional per-launch timing (sagnn_profile_*) -------------------------------------------

@@ -372,7 +372,7 @@ int dense_nn_any(const float* X, int64_t ldx, int64_t n, int din, int dout, cons
 // dW += X^T G, db += colsum(G) for any multiples of 32: 256 x 256 output blocks at most per launch.
 int dense_tn_any(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW,
                  int64_t lddw, float* db, hipStream_t s) {
-  if (din > 128 || dout > 256) return gemm_tn(X, ldx, G, ldg, n, din, dout, dW, lddw, db, s);   // more than one piece: dense_gemm.hip
+  if (din > 128 || dout > 256) return gemm_tn(X, ldx, 0, G, ldg, 0, n, 1, din, dout, dW, lddw, db, s);   // more than one piece: dense_gemm.hip
   for (int r0 = 0; r0 < din; r0 += 128) {
     const int rw = din - r0 < 128 ? din - r0 : 128;
     for (int c0 = 0; c0 < dout; c0 += 256) {
@@ -407,4 +407,15 @@ extern "C" int sagnn_dense_tn_f32(const float* X, int64_t ldx, const float* G, i
   if (!dW) return sagnn::fail(SAGNN_ERR_NULL, "dW is NULL");
   if (n == 0) return SAGNN_OK;
   return sagnn::dense_tn_any(X, ldx, G, ldg, n, din, dout, dW, dout, db, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int sagnn_dense_tn_seg_f32(const float* X, int64_t ldx, int64_t x_seg, const float* G, int64_t ldg, int64_t g_seg,
+                                      int64_t seg_rows, int n_seg, int din, int dout, float* dW, float* db, void* stream) {
+  if (seg_rows < 0 || n_seg < 0 || din < 32 || dout < 32 || (din & 31) || (dout & 31))
+    return sagnn::fail(SAGNN_ERR_DIM, "dense_tn_seg: need din, dout multiples of 32 (got %d, %d)", din, dout);
+  if (int rc = check_xy("X", X, ldx, din)) return rc;
+  if (int rc = check_xy("G", G, ldg, dout)) return rc;
+  if ((x_seg & 3) || (g_seg & 3)) return sagnn::fail(SAGNN_ERR_ALIGN, "dense_tn_seg: segment strides must be multiples of 4 floats");
+  if (!dW) return sagnn::fail(SAGNN_ERR_NULL, "dW is NULL");
+  return sagnn::gemm_tn(X, ldx, x_seg, G, ldg, g_seg, seg_rows, n_seg, din, dout, dW, dout, db, static_cast<hipStream_t>(stream));
 }

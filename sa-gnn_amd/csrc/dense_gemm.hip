@@ -122,10 +122,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_nn_kernel(const float* __res
     }
 }
 
-// C [M, N] += X^T G over rows [blockIdx.y * k_per, ...) of X [K, M] / G [K, N]; db [N] += column sums of G (blocks of row tile 0)
-__global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ G,
-                                                              int64_t ldg, float* __restrict__ C, int64_t ldc, float* __restrict__ db,
-                                                              int M, int N, int64_t K, int64_t k_per, int n_col_tiles) {
+// C [M, N] += X^T G over rows [blockIdx.y * k_per, ...) of X [K, M] / G [K, N]; db [N] += column sums of G (blocks of row tile 0).
+// The K rows come in segments of seg_rows: row k = (s, i) lives at X + s * xseg + i * ldx and G + s * gseg + i * ldg (one
+// segment = a plain matrix; the BPTT weight gradient = one segment per step, x node-major or time-major, dG time-major).
+__global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const float* __restrict__ X, int64_t ldx, int64_t xseg,
+                                                              const float* __restrict__ G, int64_t ldg, int64_t gseg,
+                                                              uint32_t seg_rows, float* __restrict__ C, int64_t ldc,
+                                                              float* __restrict__ db, int M, int N, int64_t K, int64_t k_per,
+                                                              int n_col_tiles) {
   __shared__ __attribute__((aligned(16))) float Xs[2][BK * BM];
   __shared__ __attribute__((aligned(16))) float Gs[2][BK * BN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -155,8 +159,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_tn_kernel(const float* __res
       const int kr = idx >> 5, c4 = idx & 31;
       rx[i] = rg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (k0 + kr < ke) {
-        if (m0 + 4 * c4 < M) rx[i] = *reinterpret_cast<const float4*>(X + (k0 + kr) * ldx + m0 + 4 * c4);
-        if (n0 + 4 * c4 < N) rg[i] = *reinterpret_cast<const float4*>(G + (k0 + kr) * ldg + n0 + 4 * c4);
+        const uint32_t k = (uint32_t)(k0 + kr), sg = k / seg_rows, ri = k - sg * seg_rows;   // K < 2^31 (host)
+        if (m0 + 4 * c4 < M) rx[i] = *reinterpret_cast<const float4*>(X + sg * xseg + ri * ldx + m0 + 4 * c4);
+        if (n0 + 4 * c4 < N) rg[i] = *reinterpret_cast<const float4*>(G + sg * gseg + ri * ldg + n0 + 4 * c4);
       }
     }
   };
@@ -253,9 +258,13 @@ int gemm_nn(const float* X, int64_t ldx, int64_t n, int din, int dout, const flo
   return SAGNN_OK;
 }
 
-// dW [din, dout] += X [n, din]^T @ G [n, dout], db [dout] += column sums of G (db may be NULL)
-int gemm_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n, int din, int dout, float* dW, int64_t lddw,
-            float* db, hipStream_t s) {
+// dW [din, dout] += X^T @ G over n_seg segments of seg_rows rows (row i of segment s: X + s * xseg + i * ldx, G alike),
+// db [dout] += column sums of G (db may be NULL)
+int gemm_tn(const float* X, int64_t ldx, int64_t xseg, const float* G, int64_t ldg, int64_t gseg, int64_t seg_rows, int64_t n_seg,
+            int din, int dout, float* dW, int64_t lddw, float* db, hipStream_t s) {
+  const int64_t n = seg_rows * n_seg;
+  if (n <= 0) return SAGNN_OK;
+  if (n > INT32_MAX) return fail(SAGNN_ERR_ARG, "gemm_tn: %lld rows in one call (limit 2^31 - 1)", (long long)n);
   const int mt = (din + BM - 1) / BM, nt = (dout + BN - 1) / BN;
   // split the n rows so that the launch fills the chip twice over; every split a multiple of BK rows
   int64_t splits = (2 * (int64_t)cu_count_current() + mt * nt - 1) / (mt * nt);
@@ -265,8 +274,8 @@ int gemm_tn(const float* X, int64_t ldx, const float* G, int64_t ldg, int64_t n,
   int64_t k_per = (n + splits - 1) / splits;
   k_per = (k_per + BK - 1) / BK * BK;
   splits = (n + k_per - 1) / k_per;
-  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(mt * nt), (unsigned)splits), dim3(kThreads), 0, s, X, ldx, G, ldg, dW, lddw, db,
-                     din, dout, n, k_per, nt);
+  hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)(mt * nt), (unsigned)splits), dim3(kThreads), 0, s, X, ldx, xseg, G, ldg, gseg,
+                     (uint32_t)seg_rows, dW, lddw, db, din, dout, n, k_per, nt);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }

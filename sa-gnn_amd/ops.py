@@ -580,6 +580,25 @@ def dense_tn(x: torch.Tensor, g: torch.Tensor, dW: torch.Tensor, db: torch.Tenso
     return dW
 
 
+def dense_tn_seg(x: torch.Tensor, g: torch.Tensor, dW: torch.Tensor, db: torch.Tensor | None = None):
+    """dW += sum_s x[s]^T @ g[s], db += column sums of g (sagnn_dense_tn_seg_f32): x [s, n, din], g [s, n, dout] as
+    VIEWS with any segment / row strides (unit column stride) — e.g. x.permute(1, 0, 2) of a node-major [n, t, d]
+    against gate gradients stored [t, n, 4d]: a whole BPTT's weight gradient in one launch. Accumulates."""
+    if x.dim() != 3 or g.dim() != 3 or x.shape[:2] != g.shape[:2]:
+        raise ValueError(f"dense_tn_seg: need x [s, n, din] and g [s, n, dout], got {tuple(x.shape)} / {tuple(g.shape)}")
+    for name, v in (("x", x), ("g", g)):
+        if v.dtype != torch.float32 or not v.is_cuda or v.stride(2) != 1:
+            raise ValueError(f"dense_tn_seg: {name} must be float32 on the GPU with unit column stride")
+    s_, n, din = (int(v) for v in x.shape)
+    dout = int(g.shape[2])
+    if s_ == 0 or n == 0:
+        return dW
+    check(_lib.load().sagnn_dense_tn_seg_f32(x.data_ptr(), int(x.stride(1)), int(x.stride(0)), g.data_ptr(), int(g.stride(1)),
+                                             int(g.stride(0)), n, s_, din, dout, _vec("dW", dW, din * dout),
+                                             None if db is None else _vec("db", db, dout), _stream()))
+    return dW
+
+
 def mul(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None):
     """out = a * b element-wise (sagnn_mul_f32); contiguous float32 tensors of equal size."""
     if out is None:

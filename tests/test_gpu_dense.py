@@ -42,6 +42,35 @@ def test_dense_tn(dev, n, din, dout):
     torch.testing.assert_close(dW.cpu().double(), 2 * want, rtol=1e-4, atol=4e-6 * scale + 1e-5)
 
 
+@pytest.mark.parametrize("n,t,din,dout,layout", [(1000, 5, 128, 512, "node"), (333, 12, 128, 512, "time"), (77, 3, 64, 256, "node"),
+                                                 (5000, 2, 32, 128, "time"), (19, 7, 96, 384, "node")])
+def test_dense_tn_seg(dev, n, t, din, dout, layout):
+    """sagnn_dense_tn_seg_f32: dW += sum_s x[s]^T g[s] in one launch, x node-major ([n, t, d] seen as [t, n, d]) or
+    time-major, g time-major, and a SHIFTED pairing (x steps 0..t-2 against g steps 1..t-1: the h side of the BPTT)."""
+    from sa_gnn_amd import ops
+    gen = torch.Generator(device="cpu").manual_seed(n + t + dout)
+    x = torch.randn((n, t, din), generator=gen)
+    g = torch.randn((t, n, dout), generator=gen)
+    xd = x.to(dev) if layout == "node" else x.to(dev).permute(1, 0, 2).contiguous().permute(1, 0, 2)
+    assert xd.shape == (n, t, din)
+    gd = g.to(dev)
+    dW = torch.zeros((din, dout), device=dev)
+    db = torch.zeros(dout, device=dev)
+    ops.dense_tn_seg(xd.permute(1, 0, 2), gd, dW, db)
+    want = torch.einsum("ntd,tne->de", x.double(), g.double())
+    mag = torch.einsum("ntd,tne->de", x.double().abs(), g.double().abs())
+    assert ((dW.cpu().double() - want).abs() <= 1e-4 * want.abs() + 1e-6 * mag + 1e-5).all()
+    want_b = g.double().sum((0, 1))
+    assert ((db.cpu().double() - want_b).abs() <= 1e-4 * want_b.abs() + 1e-6 * g.double().abs().sum((0, 1)) + 1e-5).all()
+    if t > 1:
+        dW2 = torch.zeros((din, dout), device=dev)
+        ops.dense_tn_seg(xd.permute(1, 0, 2)[:t - 1], gd[1:], dW2, None)
+        want2 = torch.einsum("ntd,tne->de", x[:, :t - 1].double(), g[1:].double())
+        assert ((dW2.cpu().double() - want2).abs() <= 1e-4 * want2.abs() + 1e-6 * mag + 1e-5).all()
+    with pytest.raises(ValueError):
+        ops.dense_tn_seg(xd.permute(1, 0, 2), gd[:, : n - 1], dW, None)
+
+
 @pytest.mark.parametrize("engine", ["f16x2", "f32"])
 @pytest.mark.parametrize("rows,d", [(1000, 64), (31, 64), (40007, 64), (513, 32), (70001, 32)])
 def test_attn_bwd_tail(dev, rows, d, engine):
