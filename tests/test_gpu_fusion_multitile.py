@@ -76,12 +76,14 @@ def test_interval_fusion_many_tiles_per_block(dev, d, t, n):
     _check(got, O.interval_fusion(np.ascontiguousarray(xs.transpose(1, 0, 2)), p, 16), "interval_fusion")
 
 
-@pytest.mark.parametrize("d,t,n", [(64, 2, 100_003), (64, 3, 70_001), (32, 4, 100_003)])
+@pytest.mark.parametrize("d,t,n", [(64, 2, 100_003), (64, 3, 70_001), (32, 4, 100_003), (128, 4, 70_001)])
 def test_training_forward_and_backward_many_tiles_per_block(dev, d, t, n):
     """The training forward (sagnn_lstm_fwd_train_f32 storing gates / cell + the fused LN/attention
     kernel) and the whole backward (attention-backward front and tail, LN backward, one-launch BPTT)
     at sizes where every block loops: fused output, dx and every parameter gradient against float64
-    autograd over the oracle's torch restatement."""
+    autograd over the oracle's torch restatement. d = 128 (config 3) takes the generic backward: per-step
+    gate backward + one tiled-GEMM product per step, the weight gradient as two segmented products after
+    the loop (dense_gemm.hip)."""
     from sa_gnn_amd import autograd as ag
     rng = np.random.default_rng(d + t)
     x = rng.standard_normal((n, t, d)).astype(np.float32)
