@@ -110,7 +110,7 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
     const float* __restrict__ bq, const float* __restrict__ Wk, const float* __restrict__ bk,
     const float* __restrict__ Wv, const float* __restrict__ bv, float* out, int64_t ld_out,
     int64_t n_tiles, float* __restrict__ dqkv_out, float* __restrict__ y_out, unsigned int* __restrict__ redo_ctr) {
-  static_assert(!BWD || (LP == 1 && D <= 64), "the backward front keeps a pair in one lane");
+  static_assert(!BWD || LP == 1, "the backward front keeps a pair in one lane");
   constexpr int NW = D >= 64 ? 4 : D / 16, NT = 64 * NW, KS = D / 32;
   constexpr int DK = D / 16;                    // 16 heads
   constexpr int HPW = 16 / DK;                  // heads per wave
@@ -245,7 +245,8 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
       }
       range_seg4(yr, y.x, y.y, y.z, y.w);
       if constexpr (BWD) {
-        if (y_out && r < ROWS && node0 + r / T < n) *reinterpret_cast<float4*>(y_out + (node0 * T + r) * D + fc4_) = y;
+        if (y_out && blockIdx.y == 0 && r < ROWS && node0 + r / T < n)   // d = 128: both column halves normalise the rows, one stores them
+          *reinterpret_cast<float4*>(y_out + (node0 * T + r) * D + fc4_) = y;
       }
       const int p0 = head2(y.x, y.y), p1 = head2(y.z, y.w);
       const int off = r * (D * 2) + (((fc4_ >> 3) ^ swz<D>(r)) << 4) + ((fc4_ >> 2) & 1) * 8;
@@ -482,7 +483,7 @@ static int launch_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, c
                         const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s,
                         float* dqkv = nullptr, float* y = nullptr) {
   constexpr int NW = D >= 64 ? 4 : D / 16, NB = kRows / T;
-  constexpr int LP = lanes_per_pair(T, D);
+  constexpr int LP = BWD ? 1 : lanes_per_pair(T, D);
   constexpr int GS = kRows * kRec + NB * pad_node(T) + pad_group(T);
   const size_t lds = (size_t)2 * kRows * D * 2 + (size_t)NW * 4 * GS + (size_t)(kRows + NB) * sizeof(float2) + 16;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&ln_mhsa_split_kernel<D, T, LP, BWD>), lds)) return rc;
@@ -524,10 +525,11 @@ int ln_mhsa_mean_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, in
   return dispatch_t<32>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
 }
 
-// Front of the attention backward pass on the same kernel (d in {32, 64}, 16 heads, t <= 6: one lane per pair):
+// Front of the attention backward pass on the same kernel (d in {32, 64, 128}, 16 heads, t <= 6: one lane per pair;
+// d = 128: d_k = 8, a pair's q / k / v / dk vectors take 192 of the 512 registers a one-workgroup-per-CU wave has):
 // y = LN(x) (or x), Q|K|V, attention backward -> dqkv [n*t, 3d] and, when y is not NULL, y [n*t, d].
 bool attn_bwd_front_split_supported(int d, int t, int heads) {
-  return heads == 16 && (d == 32 || d == 64) && t >= 1 && t <= 6;
+  return heads == 16 && (d == 32 || d == 64 || d == 128) && t >= 1 && t <= 6;
 }
 
 template <int D>
@@ -551,6 +553,8 @@ int attn_bwd_front_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, 
                          const float* bk, const float* Wv, const float* bv, const float* g_out, int64_t ld_g, float* dqkv,
                          float* y, hipStream_t s) {
   if (!attn_bwd_front_split_supported(d, t, heads)) return fail(SAGNN_ERR_DIM, "split attention backward front: unsupported d/t/heads");
+  if (d == 128)
+    return dispatch_bwd_t<128>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, g_out, ld_g, dqkv, y, s);
   if (d == 64)
     return dispatch_bwd_t<64>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, g_out, ld_g, dqkv, y, s);
   return dispatch_bwd_t<32>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, g_out, ld_g, dqkv, y, s);

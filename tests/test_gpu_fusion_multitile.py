@@ -113,9 +113,12 @@ def test_training_forward_and_backward_many_tiles_per_block(dev, d, t, n):
         assert not bad.any(), f"{name}: {int(bad.sum())}/{bad.size} off, worst {np.abs(a - b)[bad].max():.3e} (scale {np.abs(b).max():.3e})"
 
 
-@pytest.mark.parametrize("d,t,n", [(64, 2, 100_003), (64, 8, 70_001), (32, 3, 100_003)])
+@pytest.mark.parametrize("d,t,n", [(64, 2, 100_003), (64, 8, 70_001), (32, 3, 100_003), (128, 6, 20_011), (128, 1, 5_003)])
 def test_attn_bwd_front_many_tiles_per_block(dev, d, t, n):
-    """sagnn_attn_bwd_front_f32 alone: y = LN(x) and dQ|dK|dV against float64 autograd."""
+    """sagnn_attn_bwd_front_f32 alone: y = LN(x) and dQ|dK|dV against float64 autograd (d = 128: d_k = 8, the two
+    column halves of Q|K|V in separate workgroups, y stored by one of them)."""
+    from sa_gnn_amd import _lib
+    assert _lib.load().sagnn_attn_bwd_front_supported(d, t, 16)
     from sa_gnn_amd import autograd as ag
     rng = np.random.default_rng(d * 7 + t)
     heads, dk = 16, d // 16
