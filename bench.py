@@ -84,6 +84,10 @@ def parse():
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="gloo = rehearsal of the N>1 pipeline on ONE GPU (every rank uses cuda:0, collectives "
                         "staged through host memory); never a performance run")
+    p.add_argument("--dist-single", action="store_true",
+                   help="with --gpus 1: initialise the process group (RCCL, or gloo) with ONE rank and run the N > 1 code path — "
+                        "exchange rounds, pipelined fusion, gathers, their adjoints — through it; a check of the collective calls, "
+                        "never a performance run")
     p.add_argument("--engine", default="f16x2", choices=["f16x2", "f32", "valu"],
                    help="arithmetic engine of the fusion GEMMs for the timed steps (sagnn_set_engine); the default line also "
                         "carries a short same-run block on the exact-fp32 engine (fusion_f32_engine)")
@@ -107,14 +111,18 @@ def launch_command(n_ranks: int, argv: list, port: int) -> list:
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def self_launch(n_ranks: int, argv: list) -> int:
     """Starts the N ranks as a CHILD process (this process has not touched the GPU and never will), relays their
     output — rank 0's one JSON line on stdout — and returns the launcher's exit code."""
-    import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = _free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
     cmd = launch_command(n_ranks, argv, port)
@@ -137,16 +145,25 @@ def main():
                                      SplitIntervalRunner, SplitIntervalSharding, csr_row_slice, exchange_to_row_shards,
                                      gather_fused, make_sharding)
 
-    rehearsal = world > 1 and a.dist_backend == "gloo"
+    # --dist-single: the process group and the N > 1 code path (exchange rounds, pipelined fusion, gathers) with ONE rank —
+    # what a one-GPU box can check of the RCCL calls (argument types, devices, contiguity) before an 8-GPU node exists
+    multi = world > 1 or a.dist_single
+    rehearsal = multi and a.dist_backend == "gloo"
     if rehearsal:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
+        if world == 1:                      # --dist-single from a bare shell: a one-rank rendezvous of its own
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if a.dist_single:
+        import sa_gnn_amd.parallel as _par
+        _par.SINGLE_RANK_COLLECTIVES = True
     lib = _lib.load()
     ops.set_engine(a.engine)
 
@@ -204,7 +221,7 @@ def main():
             f"long rows {pu.info.n_long_rows}/{pi.info.n_long_rows} ({time.time() - t0:.1f}s)")
     # dataset-sized graphs: the T intervals of a layer in ONE launch (sagnn_gnn_stack_f32); the embeddings then live in
     # [T, N, d] tensors, as the model's parameters do
-    use_batch = (not synthetic_wl) and world == 1 and len(plans) == T and T > 0
+    use_batch = (not synthetic_wl) and not multi and len(plans) == T and T > 0
     batch = None
     if use_batch:
         batch = ops.SpmmBatch([pp[0] for pp in plans], [pp[1] for pp in plans])
@@ -218,7 +235,7 @@ def main():
     prm[1]["lstm_W"], prm[1]["lstm_b"] = prm[0]["lstm_W"], prm[0]["lstm_b"]     # one shared cell (model.py:141-144)
 
     t_loc = len(sh.local_intervals)
-    overlap = world > 1 and a.exchange == "alltoall"
+    overlap = multi and a.exchange == "alltoall"
     comm_dev = torch.device("cpu") if rehearsal else dev          # gloo rehearsal: collectives on host copies
     if frac:
         runner = FractionalRunner(sh, U, I, d, dev, {k: groups[k] for k in sh.local_intervals}, comm_device=comm_dev)
@@ -349,13 +366,13 @@ def main():
                 us, its = ag.gnn_stack(leaves["uEmbed"], leaves["iEmbed"], pl_u, pl_i, L, 0.5)  # [T_local, N, d] slabs, no stack copy
             finals, loss = [], 0.0
             for xs, n_rows, p in ((us, U, prm[0]), (its, I, prm[1])):
-                if world > 1:
+                if multi:
                     xs = exchange_rows(xs.to(comm_dev), sh, n_rows).to(dev)                        # [T, rows_local, d]
                 f_loc = ag.interval_fusion(xs.permute(1, 0, 2), p, heads)
                 loss = loss + f_loc.sum()                                                          # this rank's rows
-                finals.append(gather_rows(f_loc.to(comm_dev), sh, n_rows).to(dev) if world > 1 else f_loc)
+                finals.append(gather_rows(f_loc.to(comm_dev), sh, n_rows).to(dev) if multi else f_loc)
             loss.backward()
-            if world > 1:
+            if multi:
                 if rehearsal:
                     for v in shared:                      # gloo all-reduces host copies
                         gcpu = v.grad.cpu()
@@ -368,12 +385,12 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
     def allmax(x: float) -> float:
-        if world == 1:
+        if not multi:
             return x
         tt = torch.tensor([x], device=comm_dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -396,7 +413,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t1
     step_ms = [marks[s_].elapsed_time(marks[s_ + 1]) for s_ in range(a.steps)]
-    graph_mode = bool(a.graph and world == 1)
+    graph_mode = bool(a.graph and not multi)
     if graph_mode:
         # the eager pass above supplied the HIP-event records; now capture the same step once and
         # time its replays (events are not recorded inside a captured launch sequence)
@@ -420,7 +437,7 @@ def main():
         step_ms = [marks[s_].elapsed_time(marks[s_ + 1]) for s_ in range(a.steps)]
     redo_tiles = ops.range_redo_count()       # tiles the f16 x 2 kernels re-evaluated in fp32 during the timed steps (0 = fast path throughout)
     elapsed = allmax(elapsed)
-    if world > 1:
+    if multi:
         te = torch.tensor([local_launch_edges], device=comm_dev, dtype=torch.int64)
         dist.all_reduce(te)
         launch_edges_all = int(te.item())
@@ -500,7 +517,7 @@ def main():
         "config": {"workload": wl_name, "users": U, "items": I, "intervals_total": T,
                    "intervals_per_gpu": t_loc, "edges_per_interval": launch_edges_all // max(2 * T, 1),
                    "embed_dim": d, "gnn_layers": L, "heads": heads, "stages": a.stages,
-                   "exchange": a.exchange if world > 1 else "none", "scale": a.scale, "item_zipf_s": a.zipf,
+                   "exchange": a.exchange if multi else "none", "scale": a.scale, "item_zipf_s": a.zipf,
                    "launch": "hipGraph replay" if graph_mode else "eager",
                    "spmm_launches": ("one per layer for all intervals and both directions (sagnn_gnn_stack_f32)" if use_batch
                                      else "one per interval, layer and direction (sagnn_gnn_interval_f32)"),
@@ -531,7 +548,7 @@ def main():
     }
 
     # ---- the same steps on the exact-fp32 engine, same run (N = 1): what the f16 x 2 split buys ---------
-    if world == 1 and a.stages == "full" and a.engine == "f16x2" and not graph_mode:
+    if not multi and a.stages == "full" and a.engine == "f16x2" and not graph_mode:
         with ops.engine("f32"):
             step()
             sync()
@@ -547,7 +564,7 @@ def main():
         sync()
 
     # ---- N > 1: where the step time goes (extra passes, outside the timed region) ---------------
-    if world > 1 and a.stages == "full" and not a.no_breakdown:
+    if multi and a.stages == "full" and not a.no_breakdown:
         bd = {}
 
         def timed(fn, reps=3):
@@ -598,7 +615,7 @@ def main():
         result["breakdown_ms"] = bd
 
     # ---- CPU baseline + oracle checks on bounded samples (rank 0, N = 1) ------------------------
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and t_loc > 0:
+    if rank == 0 and not multi and not a.no_cpu_baseline and t_loc > 0:
         import scipy.sparse as sp
         from oracle import selfgnn_oracle as O
         from oracle import tf1_path
@@ -691,7 +708,7 @@ def main():
                                              "mean) vs oracle/selfgnn_oracle.py interval_fusion on the same propagated rows"}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

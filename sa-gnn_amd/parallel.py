@@ -36,6 +36,16 @@ import torch
 import torch.distributed as dist
 
 
+
+# bench.py --dist-single sets this: the one-rank shortcuts below are skipped and every collective is issued through a
+# one-rank process group — what a one-GPU box can check of the RCCL calls before an 8-GPU node exists
+SINGLE_RANK_COLLECTIVES = False
+
+
+def _solo(sh) -> bool:
+    return sh.world == 1 and not SINGLE_RANK_COLLECTIVES
+
+
 class IntervalSharding:
     """Static maps: interval -> rank (cyclic) and node row -> rank (contiguous, balanced)."""
 
@@ -455,7 +465,7 @@ def exchange_to_row_shards(local_out: torch.Tensor, sh: IntervalSharding, n_rows
     """local_out [T_local, N, d]: this rank's interval outputs in local order (interval
     rank + j*world at index j). Returns x [T, rows_local, d] in global interval order."""
     d = local_out.shape[-1]
-    if sh.world == 1:
+    if _solo(sh):
         return local_out                                   # already [T, N, d]; nothing to move
     lo, hi = sh.row_range(n_rows)
     x = torch.empty((sh.T, hi - lo, d), dtype=local_out.dtype, device=local_out.device)
@@ -528,7 +538,7 @@ class RowShardExchange:
         this round — it still takes part in the collective with empty sends)."""
         sh, j = self.sh, self._posted
         self._posted += 1
-        if sh.world == 1:
+        if _solo(sh):
             self.x[j].copy_(out_j[self.bounds[0]:self.bounds[1]])
             return
         if self._split is not None:           # T < world: out_j is this member's row slice of its interval
@@ -663,7 +673,7 @@ def gather_fused(final_local: torch.Tensor, sh: IntervalSharding, n_rows: int, g
     With async_op=True returns (out, finish) — call finish() before reading `out`; the collective
     runs on RCCL's stream meanwhile (e.g. under the other node type's fusion)."""
     d = final_local.shape[-1]
-    if sh.world == 1:
+    if _solo(sh):
         return (final_local, lambda: final_local) if async_op else final_local
     out = torch.empty((n_rows, d), dtype=final_local.dtype, device=final_local.device)
     bounds = sh.row_bounds(n_rows)
@@ -699,7 +709,7 @@ def gather_fused(final_local: torch.Tensor, sh: IntervalSharding, n_rows: int, g
 def _reduce_scatter_rows(g: torch.Tensor, sh: IntervalSharding, n_rows: int, group=None) -> torch.Tensor:
     """sum over ranks of g [N, d], each rank keeping its row shard [rows_local, d]."""
     lo, hi = sh.row_range(n_rows)
-    if sh.world == 1:
+    if _solo(sh):
         return g[lo:hi]
     g = g.contiguous()
     if dist.get_backend(group) == "gloo":          # gloo has no reduce-scatter: all-reduce, keep the shard
@@ -750,7 +760,7 @@ class ExchangeRowsFn(torch.autograd.Function):
     def backward(ctx, g):
         sh, n_rows = ctx.sh, ctx.n_rows
         d = g.shape[-1]
-        if sh.world == 1:
+        if _solo(sh):
             return g, None, None, None
         g = g.contiguous()
         bounds = sh.row_bounds(n_rows)

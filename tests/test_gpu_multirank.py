@@ -81,6 +81,24 @@ def test_fewer_intervals_than_ranks_split_rows_match_single_process(split):
         assert abs(a_ - b_) <= 1e-6 * abs(a_)
 
 
+@pytest.mark.parametrize("stages", ["full", "train"])
+def test_rccl_single_rank_runs_the_multi_rank_code_path(stages):
+    """What a one-GPU box can check of RCCL: `--dist-single` initialises the nccl process group with ONE rank and sends
+    the pipeline through the N > 1 code (exchange rounds posted after every interval's SpMMs, round-wise LSTM, chunked
+    and asynchronous all-gathers, the adjoints in training) with device tensors — argument types, devices, contiguity,
+    split lists. Same results as the plain single-process run."""
+    common = ["--steps", "2" if stages == "train" else "1", "--warmup", "0" if stages == "train" else "1", "--scale", "0.004",
+              "--no-cpu-baseline", "--intervals", "4", "--stages", stages]
+    one = _run([sys.executable, "bench.py"] + common)
+    rccl = _run([sys.executable, "bench.py", "--dist-single"] + common)
+    assert rccl["n_gpus"] == 1 and rccl["config"]["exchange"] == "alltoall"
+    tol = 2e-5 if stages == "train" else 0.0
+    for a_, b_ in zip(one["final_abs_mean"] + one["final_position_checksum"], rccl["final_abs_mean"] + rccl["final_position_checksum"]):
+        assert abs(a_ - b_) <= tol * abs(a_), (one["final_abs_mean"], rccl["final_abs_mean"])
+    if stages == "full":
+        assert set(rccl["breakdown_ms"]) >= {"spmm_only", "exchange_alltoall_only", "fusion_only", "exchange_allgather_only"}
+
+
 def test_rccl_two_gpus_smoke():
     """The N = 2 pipeline over RCCL itself (backend nccl); needs two visible GPUs, skipped on the 1-GPU box."""
     import torch
