@@ -46,6 +46,9 @@ WORKLOADS = {
     "gowalla-shaped": dict(users=48_653, items=52_619, nnz=600_000, t_total=3, d=64, layers=2),
     "amazon-shaped": dict(users=11_199, items=30_821, nnz=[72280, 78997, 79692, 78096, 45651], t_total=5, d=64, layers=3),
     "movielens-shaped": dict(users=24_312, items=8_681, nnz=300_000, t_total=6, d=128, layers=2),
+    # the reference's fourth dataset (yelp.sh:1: graphNum 12, gnn_layer 3; not a BASELINE config); its interaction count is
+    # unknown offline — edges per interval of the same order as the other three datasets' totals / T
+    "yelp-shaped": dict(users=19_751, items=38_386, nnz=126_000, t_total=12, d=64, layers=3),
 }
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec (MI355X_MICROARCH.md, chip-level parameters)
 

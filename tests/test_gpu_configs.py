@@ -1,6 +1,6 @@
 """BASELINE.json configs 2, 3 and 4 at their workload shape (Gowalla-shaped T = 3 / L = 2 / d = 64,
 MovieLens-shaped T = 6 / L = 2 / d = 128, Amazon-shaped T = 5 / L = 3 / d = 64 with the notebook's per-interval edge
-counts), each as ONE run of the bench entry with its CPU leg: the timed configuration's propagated rows (user-side
+counts) and the reference's fourth dataset shape (Yelp: T = 12 / L = 3 / d = 64), each as ONE run of the bench entry with its CPU leg: the timed configuration's propagated rows (user-side
 sample, item-side hubs) against oracle/c/tf1_path.c and its fused embeddings (users AND items) against the numpy
 oracle. The composite — every interval's SpMM stack into the strided slabs the fusion reads — is what the kernel
 tests at other shapes do not cover. Edges are synthetic (the dataset blobs are absent: SURVEY §8c)."""
@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 
 SHAPES = {"gowalla-shaped": dict(users=48_653, items=52_619, T=3, L=2, d=64),
           "movielens-shaped": dict(users=24_312, items=8_681, T=6, L=2, d=128),
-          "amazon-shaped": dict(users=11_199, items=30_821, T=5, L=3, d=64)}
+          "amazon-shaped": dict(users=11_199, items=30_821, T=5, L=3, d=64),
+          "yelp-shaped": dict(users=19_751, items=38_386, T=12, L=3, d=64)}      # yelp.sh:1 (not a BASELINE config): T = 12 fusion, L = 3
 
 
 def _bench(*args):
