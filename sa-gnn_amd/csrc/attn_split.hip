@@ -136,6 +136,13 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
   const int col0 = cbase + 4 * q;               // this lane's 4 of them
   const int fr = tid / LPR, fc4 = (tid % LPR) * 4;
   char* const tab = QKV + wave * QKVW;
+  // WAVE-LOCAL layer-norm moments (d = 64, T a power of two): the fill deals rows so that all T rows of a node sit in ONE
+  // wave (row 16 wave + 4 p + lane / 16 in pass p), and the node's moments meet through two lane shuffles instead of an
+  // LDS table, two workgroup barriers and a stage where NB threads work and the rest wait.
+  constexpr bool WL = D == 64 && (T & (T - 1)) == 0;
+  constexpr int PP = T >= 4 ? T / 4 : 1;        // WL: passes per node
+  constexpr int GP = T >= 4 ? 4 : T;            // WL: 16-lane row groups per node inside a pass
+  auto fill_row = [&](int p, int fr_now) { return WL ? 16 * wave + 4 * p + (lane >> 4) : p * RPP + fr_now; };
 
   float k4096 = 4096.f;
   asm volatile("" : "+v"(k4096));               // one register for the whole kernel, not a literal per use
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
     const int64_t node0 = tile * NB;
 #pragma unroll
     for (int p = 0; p < NFILL; ++p) {
-      const int r = p * RPP + fr;
+      const int r = fill_row(p, fr);
       const int nb = r / T, ts = r - nb * T;
       xr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (tile < n_tiles && r < ROWS && node0 + nb < n)
@@ -204,7 +211,41 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
     asm volatile("" : "+v"(fr_), "+v"(fc4_), "+v"(m_), "+v"(q_));
 
     // ---- layer norm moments: per row around the row mean, then the exact combination over a node's rows
-    if (apply_ln) {
+    float2 wst[NFILL];                  // WL: (mean, rstd) of the node of this thread's row in pass p
+    if constexpr (WL) {
+      if (apply_ln) {
+        float mr[NFILL], m2[NFILL];
+#pragma unroll
+        for (int p = 0; p < NFILL; ++p) {
+          mr[p] = row_sum<LPR>((xr[p].x + xr[p].y) + (xr[p].z + xr[p].w)) * (1.f / (float)D);
+          const float dx = xr[p].x - mr[p], dy = xr[p].y - mr[p], dz = xr[p].z - mr[p], dw = xr[p].w - mr[p];
+          m2[p] = row_sum<LPR>((dx * dx + dy * dy) + (dz * dz + dw * dw));
+        }
+#pragma unroll
+        for (int j = 0; j < NFILL / PP; ++j) {          // node 16 wave / T + j ... of this wave (GP row groups x PP passes)
+          float sm = 0.f;
+#pragma unroll
+          for (int i = 0; i < PP; ++i) sm += mr[j * PP + i];
+          if constexpr (GP >= 2) sm += __shfl_xor(sm, 16);
+          if constexpr (GP == 4) sm += __shfl_xor(sm, 32);
+          const float mean = sm * inv_t;
+          float q2 = 0.f;
+#pragma unroll
+          for (int i = 0; i < PP; ++i) {
+            const float dm = mr[j * PP + i] - mean;
+            q2 += m2[j * PP + i] + (float)D * dm * dm;
+          }
+          if constexpr (GP >= 2) q2 += __shfl_xor(q2, 16);
+          if constexpr (GP == 4) q2 += __shfl_xor(q2, 32);
+          const float2 st = make_float2(mean, rsqrtf(q2 * (1.f / (float)(T * D)) + eps));
+#pragma unroll
+          for (int i = 0; i < PP; ++i) wst[j * PP + i] = st;
+          // the fp32 fallback (slow_records) reads the moments from LDS: one lane per node leaves them there
+          const int r0 = fill_row(j * PP, fr_);
+          if (fc4_ == 0 && r0 % T == 0) nstat[r0 / T] = st;
+        }
+      }
+    } else if (apply_ln) {
 #pragma unroll
       for (int p = 0; p < NFILL; ++p) {
         const float mr = row_sum<LPR>((xr[p].x + xr[p].y) + (xr[p].z + xr[p].w)) * (1.f / (float)D);
@@ -233,10 +274,10 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
     RangeTrack yr = range_init();
 #pragma unroll
     for (int p = 0; p < NFILL; ++p) {
-      const int r = p * RPP + fr_;
+      const int r = fill_row(p, fr_);
       float4 y = xr[p];
       if (apply_ln) {
-        const float2 st = nstat[r < ROWS ? r / T : 0];
+        const float2 st = WL ? wst[p] : nstat[r < ROWS ? r / T : 0];
         const float ix = st.y * g4.x, iy = st.y * g4.y, iz = st.y * g4.z, iw = st.y * g4.w;
         y.x = xr[p].x * ix + (b4.x - st.x * ix);
         y.y = xr[p].y * iy + (b4.y - st.x * iy);
