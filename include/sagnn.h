@@ -392,7 +392,7 @@ int sagnn_lstm_bwd_step_f32(const float* gates, const float* cell, const float* 
                             const float* drop_scale, const float* dh_rec, int64_t ld_dhr, const float* dc_in,
                             float* dgates, float* dc_out, int64_t n, int t, int d, int ts, void* stream);
 /* Front of the attention backward pass in one launch (sagnn_attn_bwd_front_supported: d in {32, 64},
- * d_k in {2, 4}, t in {1..6, 8}; d = 128 with 16 heads and t <= 6 on the default engine): y = layer_norm(x) when apply_ln (else x), Q|K|V = y W + b, attention
+ * d_k in {2, 4}, t in {1..6, 8}; on the default engine with 16 heads also t in {12, 16}, and d = 128 with t <= 6): y = layer_norm(x) when apply_ln (else x), Q|K|V = y W + b, attention
  * backward given g_out = dL/d(mean context) [n, d] -> dqkv [n*t, 3d] (dQ | dK | dV rows) and, when
  * y_out is not NULL, y [n*t, d]. Replaces layernorm_td + dense_nn + attn_bwd of the recompute path. */
 int sagnn_attn_bwd_front_supported(int d, int t, int heads);

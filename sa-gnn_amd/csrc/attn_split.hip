@@ -101,16 +101,16 @@ __device__ __forceinline__ float row_sum(float v) {
 
 // T: intervals (compile time). LP = lanes_per_pair(T, D). d = 128: a workgroup (4 waves) covers 64 of the 128
 // output columns of each of Q, K, V; blockIdx.y picks the half (the layer norm is evaluated by both).
-// BWD (front of the attention backward pass, LP = 1): `out` is the UPSTREAM gradient dL/d(mean context) [n, d] (read),
+// BWD (front of the attention backward pass; LP as in the forward, 1 at d = 128): `out` is the UPSTREAM gradient dL/d(mean context) [n, d] (read),
 // and the kernel writes dQ|dK|dV [n*t, 3D] (dqkv_out) and, when y_out is not NULL, the normalised rows y [n*t, D].
 template <int D, int T, int LP, bool BWD>
-__global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void ln_mhsa_split_kernel(
+__global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), (D == 128 || (BWD && T >= 8)) ? 1 : 2) void ln_mhsa_split_kernel(
     const float* __restrict__ x, int64_t ld_n, int64_t ld_t, int64_t n, const float* __restrict__ gamma,
     const float* __restrict__ beta, float eps, int apply_ln, const float* __restrict__ Wq,
     const float* __restrict__ bq, const float* __restrict__ Wk, const float* __restrict__ bk,
     const float* __restrict__ Wv, const float* __restrict__ bv, float* out, int64_t ld_out,
     int64_t n_tiles, float* __restrict__ dqkv_out, float* __restrict__ y_out, unsigned int* __restrict__ redo_ctr) {
-  static_assert(!BWD || LP == 1, "the backward front keeps a pair in one lane");
+  static_assert(!BWD || D <= 64 || LP == 1, "d = 128: the backward front keeps a pair in one lane");
   constexpr int NW = D >= 64 ? 4 : D / 16, NT = 64 * NW, KS = D / 32;
   constexpr int DK = D / 16;                    // 16 heads
   constexpr int HPW = 16 / DK;                  // heads per wave
@@ -372,19 +372,26 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
       // dq_t = sum_s dz_ts k_s / sqrt(d_k), dk_s = sum_t dz_ts q_t / sqrt(d_k), dv_s = g / T sum_t p_ts. The table holds
       // q' = q log2(e) / sqrt(d_k): dk_s = sum_t dz_ts q'_t / log2(e).
       const float scale = qscale * 0.69314718055994530942f;
+      // LP lanes of a quad share a pair (T = 8 / 12: 2, T = 16: 4, as in the forward): every lane holds all keys and
+      // values, takes TQ of the queries, and the per-key sums over the queries (dk_s, sum_t p_ts) meet through quad DPP
+      // butterflies; the dK | dV rows are then stored TQ per lane.
+      auto quad_sum = [&](float v) {
+        if constexpr (LP > 1) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // lane ^ 1
+        if constexpr (LP > 2) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // lane ^ 2
+        return v;
+      };
 #pragma unroll 1
-      for (int p = lane; p < PAIRS; p += 64) {
+      for (int p = lane / LP; p < PAIRS; p += LSTEP) {
         const int hl = p % HPW, nb = p / HPW;
         const char* base = tab + ((hl * DK) >> 2) * GS + nb * (T * kRec + PN) + ((hl * DK) & 3) * 4;
         const int64_t node = node0 + nb;
         vec g = (vec)(0.f);
         if (node < n) g = *reinterpret_cast<const vec*>(out + node * ld_out + cbase + hl * DK);
         g *= inv_t;
-        vec qv[T], kv[T], vv[T], dk[T];
+        vec kv[T], vv[T], dk[T];
         float ps[T], asum[T];
 #pragma unroll
         for (int ts = 0; ts < T; ++ts) {
-          qv[ts] = HeadVec<DK>::load(base + ts * kRec, GS);
           kv[ts] = HeadVec<DK>::load(base + ts * kRec + 16, GS);
           vv[ts] = HeadVec<DK>::load(base + ts * kRec + 32, GS);
           dk[ts] = (vec)(0.f);
@@ -396,14 +403,16 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
         }
         float* const drow = dqkv_out + (node * T) * (3 * D) + cbase + hl * DK;
 #pragma unroll
-        for (int tq = 0; tq < T; ++tq) {
+        for (int i = 0; i < TQ; ++i) {
+          const int tq = part * TQ + i;
+          const vec qv = HeadVec<DK>::load(base + tq * kRec, GS);
           float a[T];
           float rs = 0.f;
 #pragma unroll
           for (int s_ = 0; s_ < T; ++s_) {
-            float z = qv[tq][0] * kv[s_][0];
+            float z = qv[0] * kv[s_][0];
 #pragma unroll
-            for (int c = 1; c < DK; ++c) z = fmaf(qv[tq][c], kv[s_][c], z);
+            for (int c = 1; c < DK; ++c) z = fmaf(qv[c], kv[s_][c], z);
             a[s_] = __builtin_amdgcn_exp2f(z);
             rs += a[s_];
           }
@@ -419,14 +428,28 @@ __global__ __launch_bounds__(64 * (D >= 64 ? 4 : D / 16), D == 128 ? 1 : 2) void
           for (int s_ = 0; s_ < T; ++s_) {
             const float dz = a[s_] * (ps[s_] - dot);
             dq += dz * kv[s_];
-            dk[s_] += dz * qv[tq];
+            dk[s_] += dz * qv;
             asum[s_] += a[s_];
           }
           if (node < n) *reinterpret_cast<vec*>(drow + tq * (3 * D)) = dq * scale;
         }
+        if constexpr (LP > 1) {
+          // through SCALAR copies: __builtin_bit_cast on an ext-vector element lvalue reads element 0 on this clang (see the forward's combine)
+#pragma unroll
+          for (int ts = 0; ts < T; ++ts) {
+#pragma unroll
+            for (int c = 0; c < DK; ++c) {
+              float v = dk[ts][c];
+              v = quad_sum(v);
+              dk[ts][c] = v;
+            }
+            asum[ts] = quad_sum(asum[ts]);
+          }
+        }
         if (node < n) {
 #pragma unroll
           for (int ts = 0; ts < T; ++ts) {
+            if (LP > 1 && ts / TQ != part) continue;       // the pair's lanes share the T rows: TQ each
             *reinterpret_cast<vec*>(drow + ts * (3 * D) + D) = dk[ts] * 0.69314718055994530942f;
             *reinterpret_cast<vec*>(drow + ts * (3 * D) + 2 * D) = g * asum[ts];
           }
@@ -524,13 +547,13 @@ static int launch_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, c
                         const float* Wv, const float* bv, float* out, int64_t ld_out, hipStream_t s,
                         float* dqkv = nullptr, float* y = nullptr) {
   constexpr int NW = D >= 64 ? 4 : D / 16, NB = kRows / T;
-  constexpr int LP = BWD ? 1 : lanes_per_pair(T, D);
+  constexpr int LP = (BWD && D == 128) ? 1 : lanes_per_pair(T, D);
   constexpr int GS = kRows * kRec + NB * pad_node(T) + pad_group(T);
   const size_t lds = (size_t)2 * kRows * D * 2 + (size_t)NW * 4 * GS + (size_t)(kRows + NB) * sizeof(float2) + 16;
   if (int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&ln_mhsa_split_kernel<D, T, LP, BWD>), lds)) return rc;
   // d = 64 / 32: ~68 KB / ~34 KB of LDS and <= 256 registers -> two waves per SIMD; d = 128: ~82 KB, one workgroup
   // per CU for each of the two column halves
-  const int per_cu = D == 128 ? 1 : D == 64 ? 2 : 4;
+  const int per_cu = (D == 128 || (BWD && T >= 8)) ? 1 : D == 64 ? 2 : 4;
   constexpr int CB = D == 128 ? 2 : 1;
   const int64_t n_tiles = (n + NB - 1) / NB;
   const int64_t want = (int64_t)cu_count_current() * per_cu / CB;
@@ -566,11 +589,14 @@ int ln_mhsa_mean_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, in
   return dispatch_t<32>(x, ld_n, ld_t, n, t, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, out, ld_out, s);
 }
 
-// Front of the attention backward pass on the same kernel (d in {32, 64, 128}, 16 heads, t <= 6: one lane per pair;
-// d = 128: d_k = 8, a pair's q / k / v / dk vectors take 192 of the 512 registers a one-workgroup-per-CU wave has):
+// Front of the attention backward pass on the same kernel (16 heads; d in {32, 64}: every T of the forward — one lane per
+// pair up to t = 6, 2 lanes at t = 8 / 12 and 4 at t = 16, one workgroup per CU above t = 8 for the registers; d = 128,
+// t <= 6: d_k = 8, one lane per pair, a pair's k / v / dk vectors take 144 of the 512 registers of a one-workgroup-per-CU wave):
 // y = LN(x) (or x), Q|K|V, attention backward -> dqkv [n*t, 3d] and, when y is not NULL, y [n*t, d].
 bool attn_bwd_front_split_supported(int d, int t, int heads) {
-  return heads == 16 && (d == 32 || d == 64 || d == 128) && t >= 1 && t <= 6;
+  if (heads != 16) return false;
+  if (d == 128) return t >= 1 && t <= 6;
+  return (d == 32 || d == 64) && ((t >= 1 && t <= 6) || t == 8 || t == 12 || t == 16);
 }
 
 template <int D>
@@ -584,6 +610,13 @@ static int dispatch_bwd_t(const float* x, int64_t ld_n, int64_t ld_t, int64_t n,
                                      const_cast<float*>(g_out), ld_g, s, dqkv, y);
   switch (t) {
     SAGNN_T_CASE(1) SAGNN_T_CASE(2) SAGNN_T_CASE(3) SAGNN_T_CASE(4) SAGNN_T_CASE(5) SAGNN_T_CASE(6)
+    case 8: case 12: case 16:
+      if constexpr (D <= 64) {
+        if (t == 8) return launch_split<D, 8, true>(x, ld_n, ld_t, n, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, const_cast<float*>(g_out), ld_g, s, dqkv, y);
+        if (t == 12) return launch_split<D, 12, true>(x, ld_n, ld_t, n, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, const_cast<float*>(g_out), ld_g, s, dqkv, y);
+        return launch_split<D, 16, true>(x, ld_n, ld_t, n, gamma, beta, eps, apply_ln, Wq, bq, Wk, bk, Wv, bv, const_cast<float*>(g_out), ld_g, s, dqkv, y);
+      }
+      [[fallthrough]];
     default: return fail(SAGNN_ERR_DIM, "split attention backward front: t = %d has no specialised kernel", t);
   }
 #undef SAGNN_T_CASE

@@ -1047,6 +1047,7 @@ int ln_mhsa_mean_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int
 
 bool attn_bwd_front_supported(int d, int t, int heads) {
   if (d == 128) return attn_bwd_front_split_supported(d, t, heads) && !force_f32_mfma();   // split engine only (attn_split.hip)
+  if (attn_bwd_front_split_supported(d, t, heads) && !force_f32_mfma()) return true;   // t = 12 / 16: split engine only
   if (!mhsa_mfma_supported(d, t, heads)) return false;
   const int dk = d / heads;
   return (dk == 2 || dk == 4) && ((t >= 1 && t <= 6) || t == 8);

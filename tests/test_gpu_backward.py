@@ -73,7 +73,7 @@ def test_autograd_function_end_to_end(dev):
 
 
 @pytest.mark.parametrize("d,t,n,heads", [(64, 3, 300, 16), (32, 2, 130, 16), (64, 1, 70, 16), (64, 5, 97, 4), (128, 3, 90, 16),
-                                          (64, 8, 41, 16), (32, 6, 53, 16), (64, 12, 19, 16),
+                                          (64, 8, 41, 16), (32, 6, 53, 16), (64, 12, 19, 16), (64, 16, 23, 16), (32, 12, 31, 16), (32, 16, 17, 16),
                                           (64, 2, 1000, 16), (64, 4, 77, 16), (64, 5, 61, 16), (64, 6, 37, 16),
                                           (32, 1, 33, 16), (32, 3, 90, 16), (32, 4, 70, 16), (32, 5, 45, 16), (32, 8, 29, 16)])
 def test_interval_fusion_backward_vs_autograd(dev, d, t, n, heads):

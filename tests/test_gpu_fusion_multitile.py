@@ -76,7 +76,7 @@ def test_interval_fusion_many_tiles_per_block(dev, d, t, n):
     _check(got, O.interval_fusion(np.ascontiguousarray(xs.transpose(1, 0, 2)), p, 16), "interval_fusion")
 
 
-@pytest.mark.parametrize("d,t,n", [(64, 2, 100_003), (64, 3, 70_001), (32, 4, 100_003), (128, 4, 70_001)])
+@pytest.mark.parametrize("d,t,n", [(64, 2, 100_003), (64, 3, 70_001), (32, 4, 100_003), (128, 4, 70_001), (64, 12, 20_011), (64, 16, 9_001)])
 def test_training_forward_and_backward_many_tiles_per_block(dev, d, t, n):
     """The training forward (sagnn_lstm_fwd_train_f32 storing gates / cell + the fused LN/attention
     kernel) and the whole backward (attention-backward front and tail, LN backward, one-launch BPTT)
@@ -113,7 +113,8 @@ def test_training_forward_and_backward_many_tiles_per_block(dev, d, t, n):
         assert not bad.any(), f"{name}: {int(bad.sum())}/{bad.size} off, worst {np.abs(a - b)[bad].max():.3e} (scale {np.abs(b).max():.3e})"
 
 
-@pytest.mark.parametrize("d,t,n", [(64, 2, 100_003), (64, 8, 70_001), (32, 3, 100_003), (128, 6, 20_011), (128, 1, 5_003)])
+@pytest.mark.parametrize("d,t,n", [(64, 2, 100_003), (64, 8, 70_001), (32, 3, 100_003), (128, 6, 20_011), (128, 1, 5_003),
+                                   (64, 12, 20_011), (64, 16, 30_001), (32, 16, 9_001), (32, 8, 20_011), (32, 12, 5_003)])
 def test_attn_bwd_front_many_tiles_per_block(dev, d, t, n):
     """sagnn_attn_bwd_front_f32 alone: y = LN(x) and dQ|dK|dV against float64 autograd (d = 128: d_k = 8, the two
     column halves of Q|K|V in separate workgroups, y stored by one of them)."""
