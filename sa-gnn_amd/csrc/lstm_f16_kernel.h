@@ -218,19 +218,12 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
     // and a residual accumulator chain per gate) are issued one at a time, and after each one a slice of
     // the gate math of tile bt-1 — a fixed list of single-instruction operations — is emitted, closed by a
     // scheduling barrier so the order survives the compiler. B fragments are requested one k-step ahead.
-    // The LAST tile's gate math has no later tile of its step to ride on: it is CARRIED into the next step and rides on
-    // that step's tile 0 (MODE 1; its h rows reach LDS a tile later than the others', behind a second barrier that
-    // stands before tile kBT - 1 reads them), and the last step's is flushed after the loop (MODE 2: gate math only).
-    // Left behind the MFMAs of its own step it was 12 % of the kernel (every dependent exp2 -> rcp chain exposed).
-    f32x4 ga[4], gl[4];              // pre-activations of the tile whose gate math is being interleaved (live across steps)
-    auto step = [&](auto recur_c, auto mode_c, int ts) {
+    auto step = [&](auto recur_c, int ts) {
       constexpr bool RECUR = decltype(recur_c)::value;
-      constexpr int MODE = decltype(mode_c)::value;
-      constexpr bool CARRY = MODE == 1;
       constexpr int KSN = RECUR ? KS : KSH;           // k-steps per tile
       constexpr int NM = 12 * KSN;                    // MFMAs per tile
       const char* const Xcur = Xp + (ts & 1) * 2 * PLANE;
-      char* const Hcur = Hp + (ts & 1) * 2 * PLANE;
+      const char* const Hcur = Hp + (ts & 1) * 2 * PLANE;
       char* const Hnxt = Hp + ((ts & 1) ^ 1) * 2 * PLANE;
       char* const Xnxt = Xp + ((ts & 1) ^ 1) * 2 * PLANE;
       // lane-derived LDS offsets recomputed per step (left loop-invariant the compiler hoists and spills them)
@@ -242,7 +235,8 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
       int xw0[2][2], xw1[2][2], xoff[2];   // pieces of the two x passes being written
       float xq[2][4], xs[2];
       uint32_t xsb[2];
-      f32x4 dv;                        // dropout scale of the tile whose gate math is being interleaved
+      f32x4 ga[4], gl[4];              // pre-activations of the tile whose gate math is being interleaved
+      f32x4 dv;                        // dropout scale of that tile
       float tt[4][4], pr[4], cn[4], u[4], hn[4], hv[4], r1[4];
       int w0[2], w1[2], hoff;
       i32x4 bf[2][2];                  // B fragments, double-buffered across k-steps
@@ -254,16 +248,12 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
         dst[0] = *reinterpret_cast<const i32x4*>(img + off);
         dst[1] = *reinterpret_cast<const i32x4*>(img + PLANE + off);
       };
-      // operation K of the gate math of tile PB (state in ga / tt / ...): one instruction each, more or less.
-      // PREV: the tile belongs to step ts - 1 (carried): its h pieces go to the buffer this step READS (other rows of it)
-      auto gate_op = [&](auto pb_c, auto k_c, auto prev_c) {
+      // operation K of the gate math of tile PB (state in ga / tt / ...): one instruction each, more or less
+      auto gate_op = [&](auto pb_c, auto k_c) {
         constexpr int PB = decltype(pb_c)::value, K = decltype(k_c)::value;
-        constexpr bool PREV = decltype(prev_c)::value;
         const int row = PB * 16 + m_;
-        const int tsg = PREV ? ts - 1 : ts;
-        char* const Hdst = PREV ? Hcur : Hnxt;
         if constexpr (K == 0) {
-          const int e_td = (row * t + tsg) * D + hid;
+          const int e_td = (row * t + ts) * D + hid;
           if constexpr (DROP) dv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, e_td * 4, 0, 0));
         } else if constexpr (K < 17) {          // the two accumulators joined: t = head + 2^-12 residual
           constexpr int k = K - 1, g = k >> 2, r = k & 3;
@@ -316,17 +306,17 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
           hoff = row * (D * 2) + (((hid >> 3) ^ swz<D>(row)) << 4) + ((hid >> 2) & 1) * 8;
         } else if constexpr (K == 115) {
           // always written: after the last step nothing reads it (no branch in the interleaved stream)
-          *reinterpret_cast<i32x2*>(Hdst + hoff) = i32x2{w0[0], w0[1]};
-          *reinterpret_cast<i32x2*>(Hdst + PLANE + hoff) = i32x2{w1[0], w1[1]};
+          *reinterpret_cast<i32x2*>(Hnxt + hoff) = i32x2{w0[0], w0[1]};
+          *reinterpret_cast<i32x2*>(Hnxt + PLANE + hoff) = i32x2{w1[0], w1[1]};
         } else if constexpr (K == 116) {
           const i32x4 hvv = {__builtin_bit_cast(int, hv[0]), __builtin_bit_cast(int, hv[1]), __builtin_bit_cast(int, hv[2]),
                              __builtin_bit_cast(int, hv[3])};
-          __builtin_amdgcn_raw_buffer_store_b128(hvv, rs_h, (row * (int)ld_h + tsg * D + hid) * 4, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(hvv, rs_h, (row * (int)ld_h + ts * D + hid) * 4, 0, 0);
           c[PB] = f32x4{cn[0], cn[1], cn[2], cn[3]};
         } else if constexpr (K == 117) {
           if constexpr (SAVE) {
-            const int e_td = (row * t + tsg) * D + hid;
-            const int go_ = (row * t + tsg) * NC + hid;
+            const int e_td = (row * t + ts) * D + hid;
+            const int go_ = (row * t + ts) * NC + hid;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const i32x4 gv = {__builtin_bit_cast(int, tt[g][0]), __builtin_bit_cast(int, tt[g][1]),
@@ -405,46 +395,31 @@ __global__ __launch_bounds__(64 * (D / 16), 1) void lstm_fwd_f16_kernel(
           constexpr bool XO = BT >= kBT - kBT / 2;     // this tile also carries two x passes
           constexpr int lo = sched_start<NM, XO>(I), hi = sched_start<NM, XO>(I + 1);
           static_for<lo, hi>([&](auto pos_c) {
-            gate_op(std::integral_constant<int, BT - 1>{}, std::integral_constant<int, sched_op<NM, XO>(decltype(pos_c)::value)>{},
-                    std::false_type{});
-          });
-        } else if constexpr (CARRY) {                  // the previous step's last tile
-          constexpr int lo = sched_start<NM, false>(I), hi = sched_start<NM, false>(I + 1);
-          static_for<lo, hi>([&](auto pos_c) {
-            gate_op(std::integral_constant<int, kBT - 1>{}, std::integral_constant<int, sched_op<NM, false>(decltype(pos_c)::value)>{},
-                    std::true_type{});
+            gate_op(std::integral_constant<int, BT - 1>{}, std::integral_constant<int, sched_op<NM, XO>(decltype(pos_c)::value)>{});
           });
         }
         __builtin_amdgcn_sched_barrier(0);
       };
       auto tile_fn = [&](auto bt_c) {
-        constexpr int BT = decltype(bt_c)::value;
         static_for<0, NM>([&](auto i_c) { slot(bt_c, i_c); });
 #pragma unroll
         for (int g = 0; g < 4; ++g) ga[g] = ahi[g], gl[g] = alo[g];
-        // the carried tile's h rows were written under tile 0; tile kBT - 1 reads them
-        if constexpr (CARRY && BT == 1) lds_barrier();
       };
-      if constexpr (MODE == 2) {       // after the last step: its last tile's gates, behind nothing
-        static_for<0, kGateOps>([&](auto pos_c) {
-          gate_op(std::integral_constant<int, kBT - 1>{}, std::integral_constant<int, kOrder48[decltype(pos_c)::value]>{},
-                  std::true_type{});
-        });
-      } else {
-        read_b(0, 0, bf[0]);
-        static_for<0, kBT>(tile_fn);
-      }
+      read_b(0, 0, bf[0]);
+      static_for<0, kBT>(tile_fn);
+      // the last tile's gates: the only part of the step the MFMAs do not cover
+      static_for<0, kGateOps>([&](auto pos_c) {
+        gate_op(std::integral_constant<int, kBT - 1>{}, std::integral_constant<int, kOrder48[decltype(pos_c)::value]>{});
+      });
     };
 
     for (int ts = 0; ts < t; ++ts) {
       if (ts + 1 < t) fetch_x(ts + 1);               // in flight under this step
-      if (ts > 0) step(std::true_type{}, std::integral_constant<int, 1>{}, ts);
-      else if (h_init != nullptr) step(std::true_type{}, std::integral_constant<int, 0>{}, ts);
-      else step(std::false_type{}, std::integral_constant<int, 0>{}, ts);   // zero initial state: the h half contributes nothing
+      if (ts > 0 || h_init != nullptr) step(std::true_type{}, ts);
+      else step(std::false_type{}, ts);               // zero initial state: the h half contributes nothing
       // x_{ts+1} went into the other buffer inside the step (its loads were issued at the top of it)
-      if (ts + 1 < t) lds_barrier();   // x_{ts+1} and h_{ts+1} of tiles 0 .. kBT - 2 are in place (the last tile's: see CARRY); x_ts / h_ts are free
+      if (ts + 1 < t) lds_barrier();   // x_{ts+1} and every wave's columns of h_{ts+1} are in place; x_ts / h_ts are free
     }
-    step(std::true_type{}, std::integral_constant<int, 2>{}, t);   // the last step's last tile
     if (range_bad(xrng)) flags[par] = 1;
     lds_barrier();            // flags settled; the images are free (the next tile's fills overwrite them)
     const bool redo = (flags[par] | flags[2]) != 0;   // block-uniform
