@@ -263,6 +263,39 @@ def test_gnn_stack_one_launch_per_layer_vs_oracle(dev, d, L, T):
         assert torch.equal(mu[k], mu2) and torch.equal(mi[k], mi2)
 
 
+def test_gnn_stack_batch_with_an_empty_interval(dev):
+    """The batched entry over intervals of which one stores NO entry (the reference's transToLsts then holds the phantom
+    (0, 0) edge: SURVEY §0.4) and one has only trailing-empty rows: bit for bit the per-interval entry, forward and
+    backward (the adjoint of the phantom edge reaches row 0 of the other node type)."""
+    from sa_gnn_amd import autograd as ag
+    from sa_gnn_amd import graph, ops
+    rng = np.random.default_rng(5)
+    U, I, T, L, d = 137, 95, 3, 2, 64
+    mats = _intervals(rng, U, I, T, (0.05,))
+    mats[1] = sp.csr_matrix((U, I), dtype=np.intc)                          # nothing happened in interval 1
+    mats[2] = sp.csr_matrix((np.ones(2, np.intc), (np.array([0, 3]), np.array([2, 5]))), shape=(U, I))
+    pairs = [graph.interval_pair(m, dev, tuning=(8, 24, 64)) for m in mats]
+    batch = ops.SpmmBatch([p[0].plan for p in pairs], [p[1].plan for p in pairs])
+    ue = torch.from_numpy(rng.standard_normal((T, U, d)).astype(np.float32)).to(dev)
+    ie = torch.from_numpy(rng.standard_normal((T, I, d)).astype(np.float32)).to(dev)
+    gu = torch.from_numpy(rng.standard_normal((T, U, d)).astype(np.float32)).to(dev)
+    gi = torch.from_numpy(rng.standard_normal((T, I, d)).astype(np.float32)).to(dev)
+    res = []
+    for plans in ((batch, None), ([p[0].plan for p in pairs], [p[1].plan for p in pairs])):
+        a, b = ue.clone().requires_grad_(True), ie.clone().requires_grad_(True)
+        ou, oi = ag.gnn_stack(a, b, plans[0], plans[1], L, 0.5)
+        ((ou * gu).sum() + (oi * gi).sum()).backward()
+        res.append((ou.detach(), oi.detach(), a.grad, b.grad))
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x, y)
+    ou = res[0][0]
+    adjs = [O.trans_to_lsts(m)[0] for m in mats]
+    tps = [O.trans_to_lsts(O.transpose(m))[0] for m in mats]
+    want_u, want_i = O.gnn_stack(ue.cpu().numpy(), ie.cpu().numpy(), adjs, tps, L, 0.5)     # [U, T, d]
+    np.testing.assert_allclose(ou.permute(1, 0, 2).cpu().numpy(), want_u, rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(res[0][1].permute(1, 0, 2).cpu().numpy(), want_i, rtol=RTOL, atol=ATOL)
+
+
 @pytest.mark.parametrize("d,L,T", [(64, 2, 3), (32, 3, 4)])
 def test_gnn_stack_backward_matches_per_interval_backward(dev, d, L, T):
     """sagnn_gnn_stack_bwd_f32 against sagnn_gnn_interval_bwd_f32 interval by interval (itself checked against
