@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SAGNN_VERSION 10301 /* 1.3.0 */
+#define SAGNN_VERSION 10302 /* 1.3.0 */
 
 enum {
   SAGNN_OK = 0,
@@ -412,6 +412,17 @@ int sagnn_lstm_bwd_supported(int d);
 int sagnn_lstm_bwd_f32(const float* x, int64_t ld_n, int64_t ld_t, const float* h, const float* gates,
                        const float* cell, const float* dh_ext, int64_t ld_dhe, const float* drop_scale,
                        const float* W, float* dx, float* dW, float* db, int64_t n, int t, int d, void* stream);
+/* sagnn_lstm_bwd_f32 with the weight gradient as a SECOND PASS on the default engine: the BPTT launch leaves out its
+ * dW product (fp32 MFMA: the larger part of its time) and stores the gate gradients time-major into the caller's
+ * scratch ([t, n, 4d] floats = sagnn_lstm_bwd_workspace_bytes, 16-byte aligned); one pass over them then takes
+ * dW += [x_s | h_{s-1}]^T dG_s on the 16-bit matrix cores over split operands, gate-gradient rows scaled by exact
+ * powers of two as in the attention tail (ARITHMETIC above). Same arguments and results otherwise; with
+ * workspace == NULL, or under SAGNN_ENGINE_F32 / SAGNN_ENGINE_VALU, the call IS sagnn_lstm_bwd_f32. */
+size_t sagnn_lstm_bwd_workspace_bytes(int64_t n, int t, int d);
+int sagnn_lstm_bwd_ws_f32(const float* x, int64_t ld_n, int64_t ld_t, const float* h, const float* gates,
+                          const float* cell, const float* dh_ext, int64_t ld_dhe, const float* drop_scale,
+                          const float* W, float* dx, float* dW, float* db, int64_t n, int t, int d, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Prediction head (reference model.py:156-173). The masked sum of item /

@@ -101,6 +101,9 @@ SIGNATURES = {
     "sagnn_lstm_bwd_supported": (c_int, [c_int]),
     "sagnn_lstm_bwd_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "sagnn_lstm_bwd_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "sagnn_lstm_bwd_ws_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "sagnn_leaky_add_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int64, c_void_p]),
     "sagnn_pair_score_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                      c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_int, c_void_p]),

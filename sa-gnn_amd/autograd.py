@@ -11,7 +11,9 @@ from . import ops
 # that the fused entries (attention-backward front + tail, one-launch BPTT) replaced.
 FUSED_ATTN_BWD = True
 FUSED_BPTT = True
-DEFERRED_DW_LIMIT = 4 << 30   # bytes of gate gradients ([t, n, 4d]) the generic BPTT may keep for the one-launch weight gradient
+DEFERRED_DW_LIMIT = 32 << 30   # bytes of gate gradients ([t, n, 4d]) a BPTT may keep for the separate weight-gradient pass
+SPLIT_DW = True                # one-launch BPTT (d = 32 / 64): weight gradient as a second pass on the f16 x 2 engine ...
+SPLIT_DW_MIN_T = 4              # ... from this many steps on (measured: T = 16 -13 %, T = 6 -8 %, T = 2 / 3 nothing: the gate gradients' HBM round trip)
 
 
 class GnnIntervalFn(torch.autograd.Function):
@@ -152,9 +154,14 @@ def lstm_bwd(x, h, gates, cell, dh, drop, W):
     dx = torch.empty((n, t, d), dtype=torch.float32, device=dev)
     dW = torch.zeros((2 * d, 4 * d), dtype=torch.float32, device=dev)
     db = torch.zeros(4 * d, dtype=torch.float32, device=dev)
-    ops.check(lib.sagnn_lstm_bwd_f32(x.data_ptr(), ld_n, ld_t, h.data_ptr(), gates.data_ptr(), cell.data_ptr(),
-                                     dh.data_ptr(), t * d, ops._ptr(drop), ops._vec("lstm_W", W, 8 * d * d),
-                                     dx.data_ptr(), dW.data_ptr(), db.data_ptr(), n, t, d, ops._stream()))
+    # scratch for the gate gradients [t, n, 4d]: with it the weight gradient is a second pass on the f16 x 2 engine
+    # (sagnn_lstm_bwd_ws_f32) instead of the BPTT launch's fp32-MFMA product
+    need = int(lib.sagnn_lstm_bwd_workspace_bytes(n, t, d))
+    ws = torch.empty(need // 4, dtype=torch.float32, device=dev) if (SPLIT_DW and t >= SPLIT_DW_MIN_T and 0 < need <= DEFERRED_DW_LIMIT) else None
+    ops.check(lib.sagnn_lstm_bwd_ws_f32(x.data_ptr(), ld_n, ld_t, h.data_ptr(), gates.data_ptr(), cell.data_ptr(),
+                                        dh.data_ptr(), t * d, ops._ptr(drop), ops._vec("lstm_W", W, 8 * d * d),
+                                        dx.data_ptr(), dW.data_ptr(), db.data_ptr(), n, t, d, ops._ptr(ws),
+                                        need if ws is not None else 0, ops._stream()))
     return dx, dW, db
 
 

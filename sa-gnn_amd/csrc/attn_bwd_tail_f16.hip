@@ -103,25 +103,50 @@ __device__ __forceinline__ float pow2_field(int field) {   // 2^(field - 127), 0
 constexpr int kUp = 6, kJump = 16;
 constexpr float kUpInv = 1.f / 64.f;   // 2^-kUp
 
-template <int D>
-__global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd_tail_f16_kernel(float* __restrict__ y, const float* __restrict__ dqkv,
-                                                                      int64_t rows, const float* __restrict__ W,
+// Where the rows come from. The attention tail (DY): one segment, x0 = y [rows, D] (overwritten with dy), g = dQKV [rows, 3 D].
+// The LSTM weight gradient (NX = 2, NQ = 4, no dy): row r = (s, i) = (step, node), s = r / seg_rows; block 0 of the left
+// operand is x_s of node i at x0 + s seg0 + i ld0, block 1 is h_{s-1} at x1 + (s - 1) seg1 + i ld1 (zero at s = 0: the
+// initial state), g = the gate gradients [t n, 4 D], rows in r order.
+struct TnArgs {
+  float* x0;
+  int64_t ld0, seg0;
+  const float* x1;
+  int64_t ld1, seg1;
+  const float* g;
+  int64_t ldg;
+  uint32_t seg_rows;
+};
+
+// NX left-operand blocks of D columns, NQ gradient blocks of D columns: dW [NX D, NQ D] += X^T G (+ db, + dy when DY).
+template <int D, int NX, int NQ, bool DY>
+__global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd_tail_f16_kernel(TnArgs src, int64_t rows,
+                                                                      const float* __restrict__ W,
                                                                       float* __restrict__ dW, float* __restrict__ db,
                                                                       int64_t n_chunks, unsigned int* __restrict__ redo_ctr) {
-  constexpr int Q3 = 3 * D;              // dQKV columns
+  static_assert(!DY || NX == 1, "dy goes over the single left operand");
+  constexpr bool DB = DY;                // column sums of G ride on the product (the LSTM's db comes from its BPTT kernel)
+  // NX = 2 has 16 dW tiles per wave: head AND residual accumulators for all of them (128 registers) spill. There the two
+  // cross products of a tile meet in a transient accumulator that is folded into the tile's head accumulator (one fma per
+  // element and chunk) while the next tile's MFMAs run.
+  constexpr bool FOLD = NX == 2;
+  constexpr int Q3 = NQ * D;             // gradient columns
+  constexpr int NS = NX + NQ;            // staged float4 per lane, sub-images per piece
   constexpr int SUB = kRows * D * 2;     // bytes of one [32][D] f16 sub-image
-  constexpr int PIECE = 4 * SUB;         // y | dQ | dK | dV
+  constexpr int PIECE = NS * SUB;        // y | dQ | dK | dV  (x | h | di | dj | df | do)
   constexpr int BUF = 2 * PIECE;         // heads, scaled residuals
+  float* const y = src.x0;
+  const float* const dqkv = src.g;
   constexpr int NWV = D / 8;             // waves per block: 8 at D = 64 (two per SIMD), 4 at D = 32 (two blocks per CU)
   constexpr int kBlock = 64 * NWV;
   constexpr int LPRW = D / 4;            // lanes per staged row: lane j holds float4 j of the row's y, dQ, dK and dV
-  constexpr int NMT = D / 16, NNT = Q3 / 16;   // dW: NMT x NNT tiles of 16 x 16
+  constexpr int NMT = NX * D / 16, NNT = Q3 / 16;   // dW: NMT x NNT tiles of 16 x 16
   constexpr int MB = 1;                  // dW tile rows per wave ...
   constexpr int NBW = NMT * NNT / NWV;   // ... and tile columns per wave (6 / 3)
   constexpr int KS1 = Q3 / 32;           // k-steps of dy (6 / 3)
   constexpr int NT1 = D / 16;            // column tiles of dy (4 / 2)
   constexpr int M1 = 1;                  // dy tiles per wave: (row tile wave / NT1, column tile wave % NT1)
-  static_assert(kBlock == kRows * LPRW && 2 * NT1 == NWV && NNT % (NWV / NMT) == 0, "unsupported D");
+  static_assert(kBlock == kRows * LPRW && (!DY || 2 * NT1 == NWV) && NWV % NMT == 0 && (NMT * NNT) % NWV == 0 && NNT % (NWV / NMT) == 0 &&
+                    (NBW + NMT - 1) / NMT <= 2, "unsupported D / NX / NQ");
 
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int* const flags = reinterpret_cast<int*>(lds + 2 * BUF);   // [0], [1]: chunk number (+1) in that buffer if it takes the fp32 path; [2]: W does
@@ -142,7 +167,7 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
   const int nt1 = wave % NT1;
   const int mt1_0 = wave / NT1;
   i32x4 wf[KS1][2];
-  {
+  if constexpr (DY) {
     RangeTrack wr = range_init();
     const float* wrow = W + (size_t)(16 * nt1 + m) * Q3 + 8 * kq;
 #pragma unroll
@@ -170,25 +195,32 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
   f32x4 hib[2], lob[2];                                  // db tiles of the columns I own (at most two)
   hib[0] = hib[1] = lob[0] = lob[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float4 stage[4];                                       // y | dQ | dK | dV: my float4 of my row
+  // element (row r, column c) of left block b, or NULL where the block is zero (h_{-1}); r < 2^31 (host)
+  auto xptr = [&](int b, uint32_t r) -> const float* {
+    const uint32_t sg = r / src.seg_rows, i = r - sg * src.seg_rows;
+    if (b == 0) return src.x0 + sg * src.seg0 + i * src.ld0;
+    return sg == 0 ? nullptr : src.x1 + (sg - 1) * src.seg1 + i * src.ld1;
+  };
+  float4 stage[NS];                                      // y | dQ | dK | dV  (x | h | di | dj | df | do): my float4 of my row
   auto fetch = [&](int64_t ch) {
     const int64_t row0 = ch * kRows;
     const int last = (int)(rows - 1 - row0 < kRows - 1 ? rows - 1 - row0 : kRows - 1);  // uniform
     const uint32_t rc = sr < last ? sr : last;           // rows past the end read the last row, zeroed below
     const bool ok = sr <= last;
-    const float* const yp = y + row0 * D + (rc * D + 4 * sc);
-    const float* const gp = dqkv + row0 * Q3 + (rc * Q3 + 4 * sc);
+    const float* const gp = dqkv + (row0 + rc) * src.ldg + 4 * sc;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const float4 val = *reinterpret_cast<const float4*>(v == 0 ? yp : gp + (v - 1) * D);
-      stage[v] = make_float4(ok ? val.x : 0.f, ok ? val.y : 0.f, ok ? val.z : 0.f, ok ? val.w : 0.f);
+    for (int v = 0; v < NS; ++v) {
+      const float* const xp = v < NX ? xptr(v, (uint32_t)(row0 + rc)) : nullptr;
+      const bool have = ok && (v >= NX || xp != nullptr);
+      const float4 val = *reinterpret_cast<const float4*>(v < NX ? (xp ? xp + 4 * sc : src.x0) : gp + (v - NX) * D);
+      stage[v] = make_float4(have ? val.x : 0.f, have ? val.y : 0.f, have ? val.z : 0.f, have ? val.w : 0.f);
     }
   };
-  // biased exponent of the largest |dQKV| of my staged row (all lanes of the row agree)
+  // biased exponent of the largest |gradient| of my staged row (all lanes of the row agree)
   auto row_exponent = [&]() -> int {
-    float mx = max3abs(max3abs(0.f, stage[1].x, stage[1].y), stage[1].z, stage[1].w);
-    mx = max3abs(max3abs(mx, stage[2].x, stage[2].y), stage[2].z, stage[2].w);
-    mx = max3abs(max3abs(mx, stage[3].x, stage[3].y), stage[3].z, stage[3].w);
+    float mx = 0.f;
+#pragma unroll
+    for (int v = NX; v < NS; ++v) mx = max3abs(max3abs(mx, stage[v].x, stage[v].y), stage[v].z, stage[v].w);
     return group_max<LPRW>(__builtin_bit_cast(int, mx)) >> 23;
   };
   // split the staged row into buffer `b` at the scales described above; `id` = chunk number + 1 marks the buffer for the fp32 path
@@ -198,15 +230,20 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
     const float s = pow2_field(254 - k);               // dQKV row scale
     const float f = pow2_field(127 + k - E + kUp);     // y row scale
     char* const dst = buf + img_off<D>(sr, sc >> 1) + (sc & 1) * 8;
-    const float4 yr = stage[0];
-    const float4 yv = make_float4(yr.x * f, yr.y * f, yr.z * f, yr.w * f);
-    {
+    bool bad = e == 255;
+#pragma unroll
+    for (int v = 0; v < NX; ++v) {
+      const float4 yr = stage[v];
+      const float4 yv = make_float4(yr.x * f, yr.y * f, yr.z * f, yr.w * f);
       const int p0 = head2(yv.x, yv.y), p1 = head2(yv.z, yv.w);
-      *reinterpret_cast<i32x2*>(dst) = i32x2{p0, p1};
-      *reinterpret_cast<i32x2*>(dst + PIECE) = i32x2{tail2(p0, yv.x, yv.y, k4096), tail2(p1, yv.z, yv.w, k4096)};
+      *reinterpret_cast<i32x2*>(dst + v * SUB) = i32x2{p0, p1};
+      *reinterpret_cast<i32x2*>(dst + v * SUB + PIECE) = i32x2{tail2(p0, yv.x, yv.y, k4096), tail2(p1, yv.z, yv.w, k4096)};
+      const float ys = maxabs_acc(maxabs3(yr.x, yr.y, yr.z), yr.w);       // the raw segment: small as a whole?
+      const float yt = maxabs_acc(maxabs3(yv.x, yv.y, yv.z), yv.w);       // the scaled one: does it fit?
+      bad = bad || yt >= kF16Lim || (ys > 0.f && ys < 6.103515625e-05f);
     }
 #pragma unroll
-    for (int v = 1; v < 4; ++v) {
+    for (int v = NX; v < NS; ++v) {
       int h0, t0, h1, t1;
       split2_scaled(stage[v].x, stage[v].y, s, k4096, h0, t0);
       split2_scaled(stage[v].z, stage[v].w, s, k4096, h1, t1);
@@ -220,9 +257,7 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
       *reinterpret_cast<short*>(ones + (b * 2 + 0) * (kRows * 2) + sr * 2) = (short)oh;
       *reinterpret_cast<short*>(ones + (b * 2 + 1) * (kRows * 2) + sr * 2) = (short)ot;
     }
-    const float ys = maxabs_acc(maxabs3(yr.x, yr.y, yr.z), yr.w);       // the raw segment: small as a whole?
-    const float yt = maxabs_acc(maxabs3(yv.x, yv.y, yv.z), yv.w);       // the scaled one: does it fit?
-    if (yt >= kF16Lim || (ys > 0.f && ys < 6.103515625e-05f) || e == 255) flags[b] = id;
+    if (bad) flags[b] = id;
   };
 
   int64_t ch = blockIdx.x;
@@ -265,7 +300,10 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
 #pragma unroll
           for (int a = 0; a < MB; ++a)
 #pragma unroll
-            for (int b = 0; b < NBW; ++b) hiw[a][b] *= g, low[a][b] *= g;
+            for (int b = 0; b < NBW; ++b) {
+              hiw[a][b] *= g;
+              if constexpr (!FOLD) low[a][b] *= g;
+            }
           hib[0] *= g, hib[1] *= g, lob[0] *= g, lob[1] *= g;
         }
         e_acc = e_run;
@@ -275,25 +313,36 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
         i32x4 a1[MB], a2[MB];
 #pragma unroll
         for (int a = 0; a < MB; ++a) {
-          a1[a] = read_tr<D>(buf, wm * MB + a, lane_);
-          a2[a] = read_tr<D>(buf + PIECE, wm * MB + a, lane_);
+          const int mt = wm * MB + a;                       // tile row of dW = 16 columns of left block 16 mt / D
+          a1[a] = read_tr<D>(buf + (16 * mt / D) * SUB, (16 * mt % D) / 16, lane_);
+          a2[a] = read_tr<D>(buf + (16 * mt / D) * SUB + PIECE, (16 * mt % D) / 16, lane_);
         }
         // the rows' factors as an A operand whose 16 M rows are all equal: A[.][k = 8 kq + j] = factor of row 8 kq + j
+        f32x4 lt_prev = {0.f, 0.f, 0.f, 0.f};
         const i32x4 o1 = *reinterpret_cast<const i32x4*>(ones + (cur * 2 + 0) * (kRows * 2) + 16 * kq_);
         const i32x4 o2 = *reinterpret_cast<const i32x4*>(ones + (cur * 2 + 1) * (kRows * 2) + 16 * kq_);
 #pragma unroll
         for (int b = 0; b < NBW; ++b) {
           const int col = 16 * (wn * NBW + b);              // dQKV column of the tile
-          const char* const sub = buf + (1 + col / D) * SUB;
+          const char* const sub = buf + (NX + col / D) * SUB;
           const i32x4 b1 = read_tr<D>(sub, (col % D) / 16, lane_);
           const i32x4 b2 = read_tr<D>(sub + PIECE, (col % D) / 16, lane_);
 #pragma unroll
           for (int a = 0; a < MB; ++a) {
-            low[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a2[a]), __builtin_bit_cast(f16x8, b1), low[a][b], 0, 0, 0);
-            low[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a1[a]), __builtin_bit_cast(f16x8, b2), low[a][b], 0, 0, 0);
-            hiw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a1[a]), __builtin_bit_cast(f16x8, b1), hiw[a][b], 0, 0, 0);
+            if constexpr (FOLD) {
+              static_assert(MB == 1, "one transient accumulator in flight");
+              f32x4 lt = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a2[a]), __builtin_bit_cast(f16x8, b1), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+              lt = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a1[a]), __builtin_bit_cast(f16x8, b2), lt, 0, 0, 0);
+              hiw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a1[a]), __builtin_bit_cast(f16x8, b1), hiw[a][b], 0, 0, 0);
+              if (b > 0) hiw[a][b - 1] += lt_prev * kLoInv;       // the previous tile's cross terms: its MFMAs have drained by now
+              lt_prev = lt;
+            } else {
+              low[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a2[a]), __builtin_bit_cast(f16x8, b1), low[a][b], 0, 0, 0);
+              low[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a1[a]), __builtin_bit_cast(f16x8, b2), low[a][b], 0, 0, 0);
+              hiw[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a1[a]), __builtin_bit_cast(f16x8, b1), hiw[a][b], 0, 0, 0);
+            }
           }
-          if (bias_owner(b, NMT, NBW) == wm) {   // wave-uniform
+          if (DB && bias_owner(b, NMT, NBW) == wm) {   // wave-uniform
             const int sl = bias_slot(b, NMT, NBW);   // a constant once the loop is unrolled
             lob[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, o2), __builtin_bit_cast(f16x8, b1), lob[sl], 0, 0, 0);
             lob[sl] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, o1), __builtin_bit_cast(f16x8, b2), lob[sl], 0, 0, 0);
@@ -301,11 +350,12 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
           }
           __builtin_amdgcn_sched_barrier(0);   // one tile column's operands in flight at a time
         }
+        if constexpr (FOLD) hiw[0][NBW - 1] += lt_prev * kLoInv;
       }
       // ---- dy[:, 16 nt1 .. + 15] = dQKV @ W^T for my row tiles: dQKV read row-wise
-      const auto rs = __builtin_amdgcn_make_buffer_rsrc(y + row0 * D, 0, rows_valid * D * 4, 0x00020000);
+      const auto rs = __builtin_amdgcn_make_buffer_rsrc(y + row0 * D, 0, DY ? rows_valid * D * 4 : 0, 0x00020000);
 #pragma unroll
-      for (int t1 = 0; t1 < M1; ++t1) {
+      for (int t1 = 0; t1 < (DY ? M1 : 0); ++t1) {
         const int mt = mt1_0 + t1;
         const int row = 16 * mt + m_;
         f32x4 hi = {0.f, 0.f, 0.f, 0.f}, lo = {0.f, 0.f, 0.f, 0.f};
@@ -330,23 +380,30 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
     } else {
       // ---- this chunk (or W) is outside the window: fp32 fmaf chains. dW first (it reads y), then dy.
       if (tid == 0 && redo_ctr) atomicAdd(redo_ctr, 1u);
-      for (int idx = tid; idx < D * Q3; idx += kBlock) {
+      for (int idx = tid; idx < NX * D * Q3; idx += kBlock) {
         const int i = idx / Q3, o = idx - i * Q3;
         float acc = 0.f;
-        for (int r = 0; r < rows_valid; ++r) acc = fmaf(y[(row0 + r) * D + i], dqkv[(row0 + r) * Q3 + o], acc);
+        for (int r = 0; r < rows_valid; ++r) {
+          const float* const xp = xptr(i / D, (uint32_t)(row0 + r));
+          if (xp) acc = fmaf(xp[i % D], dqkv[(row0 + r) * src.ldg + o], acc);
+        }
         atomicAdd(dW + idx, acc);
       }
-      for (int o = tid; o < Q3; o += kBlock) {
-        float acc = 0.f;
-        for (int r = 0; r < rows_valid; ++r) acc += dqkv[(row0 + r) * Q3 + o];
-        atomicAdd(db + o, acc);
+      if constexpr (DB) {
+        for (int o = tid; o < Q3; o += kBlock) {
+          float acc = 0.f;
+          for (int r = 0; r < rows_valid; ++r) acc += dqkv[(row0 + r) * src.ldg + o];
+          atomicAdd(db + o, acc);
+        }
       }
-      __syncthreads();
-      for (int idx = tid; idx < rows_valid * D; idx += kBlock) {
-        const int r = idx / D, i = idx - r * D;
-        float acc = 0.f;
-        for (int o = 0; o < Q3; ++o) acc = fmaf(dqkv[(row0 + r) * Q3 + o], W[(size_t)i * Q3 + o], acc);
-        y[(row0 + r) * D + i] = acc;
+      if constexpr (DY) {
+        __syncthreads();
+        for (int idx = tid; idx < rows_valid * D; idx += kBlock) {
+          const int r = idx / D, i = idx - r * D;
+          float acc = 0.f;
+          for (int o = 0; o < Q3; ++o) acc = fmaf(dqkv[(row0 + r) * Q3 + o], W[(size_t)i * Q3 + o], acc);
+          y[(row0 + r) * D + i] = acc;
+        }
       }
     }
     int e_next = e_run;
@@ -378,26 +435,29 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
       const int mt = wm * MB + a, nt = wn * NBW + b;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        atomicAdd(dW + (size_t)(16 * mt + 4 * kq + r) * Q3 + 16 * nt + m, fmaf(low[a][b][r], kLoInv, hiw[a][b][r]) * u1 * u2);
+        atomicAdd(dW + (size_t)(16 * mt + 4 * kq + r) * Q3 + 16 * nt + m,
+                  (FOLD ? hiw[a][b][r] : fmaf(low[a][b][r], kLoInv, hiw[a][b][r])) * u1 * u2);
     }
 #pragma unroll
   for (int b = 0; b < NBW; ++b)
-    if (bias_owner(b, NMT, NBW) == wm && kq == 0) {   // every C row of a ones tile holds the column sums: row 0 speaks
+    if (DB && bias_owner(b, NMT, NBW) == wm && kq == 0) {   // every C row of a ones tile holds the column sums: row 0 speaks
       const int sl = bias_slot(b, NMT, NBW);
       const float v0 = fmaf(sl == 0 ? lob[0][0] : lob[1][0], kLoInv, sl == 0 ? hib[0][0] : hib[1][0]);
       atomicAdd(db + 16 * (wn * NBW + b) + m, v0 * u1 * u2);
     }
 }
 
-template <int D>
-int launch(float* y, const float* dqkv, int64_t rows, const float* W, float* dW, float* db, hipStream_t s) {
-  const size_t lds = (size_t)2 * 2 * 4 * kRows * D * 2 + 32 + 2 * kRows * 4 + 4 * kRows * 2 + kRows * 4;   // 64 KB of images at D = 64 + flags, row scales
-  if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_tail_f16_kernel<D>), lds)) return rc;
+template <int D, int NX, int NQ, bool DY>
+int launch(const TnArgs& src, int64_t rows, const float* W, float* dW, float* db, hipStream_t s) {
+  if (rows > INT32_MAX) return sagnn::fail(SAGNN_ERR_ARG, "f16 x 2 weight-gradient kernel: %lld rows in one call (limit 2^31 - 1)", (long long)rows);
+  // images: 64 KB at D = 64 for the attention tail (y | dQ | dK | dV), 96 KB for the LSTM (x | h | 4 gates); + flags, row scales
+  const size_t lds = (size_t)2 * 2 * (NX + NQ) * kRows * D * 2 + 32 + 2 * kRows * 4 + 4 * kRows * 2 + kRows * 4;
+  if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&attn_bwd_tail_f16_kernel<D, NX, NQ, DY>), lds)) return rc;
   const int64_t n_chunks = (rows + kRows - 1) / kRows;
   const int64_t want = (D == 64 ? 1 : 2) * (int64_t)sagnn::cu_count_current();
   const int64_t blocks = n_chunks < want ? n_chunks : want;
-  hipLaunchKernelGGL(attn_bwd_tail_f16_kernel<D>, dim3((unsigned)blocks), dim3(D == 64 ? 512 : 256), lds, s, y, dqkv, rows, W, dW,
-                     db, n_chunks, sagnn::redo_counter());
+  hipLaunchKernelGGL((attn_bwd_tail_f16_kernel<D, NX, NQ, DY>), dim3((unsigned)blocks), dim3(D == 64 ? 512 : 256), lds, s, src, rows, W,
+                     dW, db, n_chunks, sagnn::redo_counter());
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
@@ -408,9 +468,23 @@ namespace sagnn {
 
 int attn_bwd_tail_f16(float* y, const float* dqkv, int64_t rows, int d, const float* Wqkv, float* dWqkv, float* dbqkv,
                       hipStream_t s) {
-  if (d == 64) return launch<64>(y, dqkv, rows, Wqkv, dWqkv, dbqkv, s);
-  if (d == 32) return launch<32>(y, dqkv, rows, Wqkv, dWqkv, dbqkv, s);
+  const TnArgs src = {y, (int64_t)d, 0, nullptr, 0, 0, dqkv, (int64_t)3 * d, (uint32_t)(rows > 0 ? rows : 1)};   // one segment
+  if (d == 64) return launch<64, 1, 3, true>(src, rows, Wqkv, dWqkv, dbqkv, s);
+  if (d == 32) return launch<32, 1, 3, true>(src, rows, Wqkv, dWqkv, dbqkv, s);
   return fail(SAGNN_ERR_DIM, "f16 attn_bwd_tail: d must be 32 or 64 (got %d)", d);
+}
+
+// dW [2d, 4d] += sum over steps of [x_s | h_{s-1}]^T dG_s: the LSTM's weight gradient from the gate gradients the BPTT
+// kernel stored time-major (dg [t, n, 4d]), x [n, t, d] in its node / interval strides, h [n, t, d] dense (un-dropped),
+// h_{-1} = 0. Same engine, same GRADIENT RANGE scheme as the attention tail: gate-gradient rows enter at power-of-two
+// scales, chunks outside the window take the fp32 path.
+int lstm_dw_f16(const float* x, int64_t ld_n, int64_t ld_t, const float* h, const float* dg, int64_t n, int t, int d, float* dW,
+                hipStream_t s) {
+  if (n <= 0 || t <= 0) return SAGNN_OK;
+  const TnArgs src = {const_cast<float*>(x), ld_n, ld_t, h, (int64_t)t * d, (int64_t)d, dg, (int64_t)4 * d, (uint32_t)n};
+  if (d == 64) return launch<64, 2, 4, false>(src, n * t, nullptr, dW, nullptr, s);
+  if (d == 32) return launch<32, 2, 4, false>(src, n * t, nullptr, dW, nullptr, s);
+  return fail(SAGNN_ERR_DIM, "f16 lstm_dw: d must be 32 or 64 (got %d)", d);
 }
 
 }  // namespace sagnn

@@ -70,6 +70,9 @@ int ln_mhsa_mean_mfma(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int
 // attn_bwd_tail_f16.hip: dy / dW / db of the three dense layers on the f16 engine (d = 32 / 64)
 int attn_bwd_tail_f16(float* y, const float* dqkv, int64_t rows, int d, const float* Wqkv, float* dWqkv, float* dbqkv,
                       hipStream_t s);
+// same kernel, LSTM form: dW [2d, 4d] += sum_s [x_s | h_{s-1}]^T dG_s from gate gradients stored time-major [t, n, 4d]
+int lstm_dw_f16(const float* x, int64_t ld_n, int64_t ld_t, const float* h, const float* dg, int64_t n, int t, int d, float* dW,
+                hipStream_t s);
 bool attn_bwd_front_split_supported(int d, int t, int heads);   // attn_split.hip: the same on the f16 engine (t <= 6)
 int attn_bwd_front_split(const float* x, int64_t ld_n, int64_t ld_t, int64_t n, int t, int d, int heads, const float* gamma,
                          const float* beta, float eps, int apply_ln, const float* Wq, const float* bq, const float* Wk,

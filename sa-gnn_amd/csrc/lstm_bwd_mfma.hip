@@ -70,12 +70,14 @@ __device__ __forceinline__ float fast_tanh(float x) {
 // reads (MFMA 2) and the row-major float4 fill are all bank-conflict free.
 __device__ __forceinline__ int swz(int row) { return (row & 15) ^ ((row & 1) << 3); }
 
-template <int D>
+// DW = false: the weight-gradient product (MFMA 2: 63 % of the kernel's time on the fp32 matrix pipe) is left out and the
+// gate gradients leave instead, time-major ([t, n, 4D] at dg_out): lstm_dw_f16.hip takes dW from them on the f16 x 2 engine.
+template <int D, bool DW>
 __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
     const float* __restrict__ x, int64_t ld_n, int64_t ld_t, const float* __restrict__ h,
     const float* __restrict__ gates, const float* __restrict__ cell, const float* __restrict__ dh_ext,
     int64_t ld_dhe, const float* __restrict__ drop, const float* __restrict__ W, float* __restrict__ dx,
-    float* __restrict__ dW, float* __restrict__ db, int64_t n, int t, int64_t n_chunks) {
+    float* __restrict__ dW, float* __restrict__ db, int64_t n, int t, int64_t n_chunks, float* __restrict__ dg_out) {
   constexpr int NC = 4 * D;         // gate columns
   constexpr int S4 = NC / 4;        // float4 slots per dG row
   constexpr int XT = D / 32;        // column tiles of x (and of h)
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
   int ts = t - 1;
   if (ch < n_chunks) {
     prefetch(ch * kRows, ts);
-    prefetch_a2(ch * kRows, ts);
+    if constexpr (DW) prefetch_a2(ch * kRows, ts);
   }
   BSTAMP_DECL;
   while (ch < n_chunks) {
@@ -260,6 +262,15 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
       dbs[1][0] += o_j.x, dbs[1][1] += o_j.y, dbs[1][2] += o_j.z, dbs[1][3] += o_j.w;
       dbs[2][0] += o_f.x, dbs[2][1] += o_f.y, dbs[2][2] += o_f.z, dbs[2][3] += o_f.w;
       dbs[3][0] += o_o.x, dbs[3][1] += o_o.y, dbs[3][2] += o_o.z, dbs[3][3] += o_o.w;
+      if constexpr (!DW) {
+        if (valid) {
+          float* const go = dg_out + ((int64_t)ts * n + row0 + row) * NC + 4 * pc4_;
+          *reinterpret_cast<float4*>(go) = o_i;
+          *reinterpret_cast<float4*>(go + D) = o_j;
+          *reinterpret_cast<float4*>(go + 2 * D) = o_f;
+          *reinterpret_cast<float4*>(go + 3 * D) = o_o;
+        }
+      }
     }
     BSTAMP(0);
     __syncthreads();  // dG complete; dhr consumed
@@ -269,11 +280,13 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
     // in flight under both MFMA phases ----------------------------------------------------------------
     const bool do_w = !h_side || ts > 0;  // h_{-1} = 0 contributes nothing
     float a2[16];
+    if constexpr (DW) {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) a2[kk] = (row0 + 2 * kk + kh_ < n) ? a2n[kk] : 0.f;
+      for (int kk = 0; kk < 16; ++kk) a2[kk] = (row0 + 2 * kk + kh_ < n) ? a2n[kk] : 0.f;
+    }
     if (nch < n_chunks) {
       prefetch(nch * kRows, nts);
-      prefetch_a2(nch * kRows, nts);
+      if constexpr (DW) prefetch_a2(nch * kRows, nts);
     }
     BSTAMP(2);
 
@@ -323,7 +336,7 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
     // ---- MFMA 2: dW[32ta .. , :] += [x_t | h_{t-1}]^T dG. h_{-1} = 0: nothing to do for the h side at
     // ts = 0 — expressed as a zero trip count of a rolled loop, not as a branch around the block (with
     // a branch the compiler keeps two copies of the 128 accumulators and spills).
-    {
+    if constexpr (DW) {
       // B operands are read one group of k-steps ahead (an MFMA does not cover an LDS round trip)
       constexpr int GK = NTB >= 8 ? 2 : 4;
       constexpr int NG = 16 / GK;
@@ -370,12 +383,14 @@ __global__ __launch_bounds__(kBlock, 1) void lstm_bwd_mfma_kernel(
 
   BSTAMP_FLUSH;
   // ---- flush: dW tiles with float atomics, db through an LDS reduction over the row groups ------
+  if constexpr (DW) {
 #pragma unroll
-  for (int j = 0; j < NTB; ++j) {
-    const int tb = tb0 + j * WPT;
+    for (int j = 0; j < NTB; ++j) {
+      const int tb = tb0 + j * WPT;
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      atomicAdd(dW + (size_t)(32 * ta + crow(r, kh)) * NC + 32 * tb + li, accw[j][r]);
+      for (int r = 0; r < 16; ++r)
+        atomicAdd(dW + (size_t)(32 * ta + crow(r, kh)) * NC + 32 * tb + li, accw[j][r]);
+    }
   }
 #pragma unroll
   for (int g = 0; g < 4; ++g)
@@ -402,17 +417,17 @@ int cu_count() {
   return cus;
 }
 
-template <int D>
+template <int D, bool DW = true>
 int launch(const float* x, int64_t ld_n, int64_t ld_t, const float* h, const float* gates, const float* cell,
            const float* dh_ext, int64_t ld_dhe, const float* drop, const float* W, float* dx, float* dW, float* db,
-           int64_t n, int t, hipStream_t s) {
+           int64_t n, int t, hipStream_t s, float* dg_out = nullptr) {
   const int64_t n_chunks = (n + kRows - 1) / kRows;
   const int64_t blocks = n_chunks < cu_count() ? n_chunks : cu_count();
   const int nq = 4 * D / 8, ql = nq - (D == 64 ? 2 : 0), nw1 = 2 * D / 32;
   const size_t lds = (size_t)kRows * (4 * D + D) * sizeof(float) + (size_t)nw1 * ql * 64 * sizeof(float4);
-  if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_bwd_mfma_kernel<D>), lds)) return rc;
-  hipLaunchKernelGGL(lstm_bwd_mfma_kernel<D>, dim3((unsigned)blocks), dim3(kBlock), lds, s, x, ld_n, ld_t, h, gates,
-                     cell, dh_ext, ld_dhe, drop, W, dx, dW, db, n, t, n_chunks);
+  if (int rc = sagnn::ensure_dynamic_lds(reinterpret_cast<const void*>(&lstm_bwd_mfma_kernel<D, DW>), lds)) return rc;
+  hipLaunchKernelGGL((lstm_bwd_mfma_kernel<D, DW>), dim3((unsigned)blocks), dim3(kBlock), lds, s, x, ld_n, ld_t, h, gates,
+                     cell, dh_ext, ld_dhe, drop, W, dx, dW, db, n, t, n_chunks, dg_out);
   SAGNN_HIP_TRY(hipGetLastError());
   return SAGNN_OK;
 }
@@ -440,6 +455,42 @@ extern "C" int sagnn_lstm_bwd_f32(const float* x, int64_t ld_n, int64_t ld_t, co
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (d == 64) return launch<64>(x, ld_n, ld_t, h, gates, cell, dh_ext, ld_dhe, drop_scale, W, dx, dW, db, n, t, s);
   return launch<32>(x, ld_n, ld_t, h, gates, cell, dh_ext, ld_dhe, drop_scale, W, dx, dW, db, n, t, s);
+}
+
+extern "C" size_t sagnn_lstm_bwd_workspace_bytes(int64_t n, int t, int d) {
+  if (n <= 0 || t <= 0 || d <= 0) return 0;
+  return (size_t)n * (size_t)t * 4 * (size_t)d * sizeof(float);
+}
+
+extern "C" int sagnn_lstm_bwd_ws_f32(const float* x, int64_t ld_n, int64_t ld_t, const float* h, const float* gates,
+                                     const float* cell, const float* dh_ext, int64_t ld_dhe, const float* drop_scale,
+                                     const float* W, float* dx, float* dW, float* db, int64_t n, int t, int d,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  // the exact-fp32 engines keep the one-launch form (its dW product IS the fp32 MFMA); so does a call without scratch
+  if (!workspace || sagnn::force_f32_mfma() || sagnn::force_valu())
+    return sagnn_lstm_bwd_f32(x, ld_n, ld_t, h, gates, cell, dh_ext, ld_dhe, drop_scale, W, dx, dW, db, n, t, d, stream);
+  if (n < 0 || t < 1) return sagnn::fail(SAGNN_ERR_DIM, "bad n/t");
+  if (!sagnn_lstm_bwd_supported(d)) return sagnn::fail(SAGNN_ERR_DIM, "lstm_bwd: d must be 32 or 64 (got %d)", d);
+  if (!x || !h || !gates || !cell || !dh_ext || !W || !dx || !dW || !db)
+    return sagnn::fail(SAGNN_ERR_NULL, "null tensor pointer");
+  if (ld_n < d || (t > 1 && ld_t < d) || ld_dhe < (int64_t)t * d)
+    return sagnn::fail(SAGNN_ERR_ARG, "strides smaller than the rows they address");
+  if (ld_n >= (1 << 25) || ld_dhe >= (1 << 25) || (int64_t)t * d >= (1 << 20))
+    return sagnn::fail(SAGNN_ERR_ARG, "lstm_bwd: row strides must stay below 2^25 floats (32-bit lane offsets)");
+  if ((ld_dhe & 3) || (ld_n & 3) || (ld_t & 3) || !sagnn::aligned16(x) || !sagnn::aligned16(h) || !sagnn::aligned16(dh_ext) ||
+      !sagnn::aligned16(gates) || !sagnn::aligned16(cell) || !sagnn::aligned16(W) || !sagnn::aligned16(workspace) ||
+      (drop_scale && !sagnn::aligned16(drop_scale)))
+    return sagnn::fail(SAGNN_ERR_ALIGN, "lstm_bwd: need 16-byte aligned rows");
+  if (workspace_bytes < sagnn_lstm_bwd_workspace_bytes(n, t, d))
+    return sagnn::fail(SAGNN_ERR_WORKSPACE, "lstm_bwd: workspace of %zu bytes, need %zu", workspace_bytes,
+                       sagnn_lstm_bwd_workspace_bytes(n, t, d));
+  if (n == 0) return SAGNN_OK;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  float* const dg = static_cast<float*>(workspace);
+  if (int rc = d == 64 ? launch<64, false>(x, ld_n, ld_t, h, gates, cell, dh_ext, ld_dhe, drop_scale, W, dx, dW, db, n, t, s, dg)
+                       : launch<32, false>(x, ld_n, ld_t, h, gates, cell, dh_ext, ld_dhe, drop_scale, W, dx, dW, db, n, t, s, dg))
+    return rc;
+  return sagnn::lstm_dw_f16(x, ld_n, ld_t, h, dg, n, t, d, dW, s);
 }
 
 #ifdef SAGNN_STAMPS

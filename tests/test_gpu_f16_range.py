@@ -143,6 +143,59 @@ def _zero_bias_params(d, rng, dev):
 GATE_ABS = 5e-7
 
 
+@pytest.mark.parametrize("pattern", ["blocks", "mixed", "rising", "tiny"])
+@pytest.mark.parametrize("d,t,n", [(64, 5, 20_011), (32, 6, 12_345), (64, 1, 5_003)])
+def test_lstm_weight_gradient_pass_at_any_gradient_scale(dev, d, t, n, pattern):
+    """sagnn_lstm_bwd_ws_f32: the BPTT launch without its dW product + the weight gradient as a second pass over the
+    stored gate gradients on the f16 x 2 engine (the attention tail's kernel in its LSTM form: [x_s | h_{s-1}] against
+    dG_s, rows of dG scaled by exact powers of two). Nodes whose upstream gradient is 1, 1e-6, 1e-9, 1e-12 in one call:
+    dx and db are the one-launch kernel's bit for bit (same code), the gate gradients in the scratch are what the float64
+    product is taken from, and dW must match it to 1e-6 of the sum of its terms' magnitudes. Every column of dW sums all
+    rows, so the pattern that a kernel flushing small rows cannot pass is 'tiny': ALL rows are 1e-12 .. 1e-15 there."""
+    from sa_gnn_amd import _lib, ops
+    from sa_gnn_amd.model import random_fusion_params
+    lib = _lib.load()
+    rng = np.random.default_rng(d + t + len(pattern))
+    g = torch.Generator(device="cpu").manual_seed(d * 3 + t)
+    x = (torch.rand((n, t, d), generator=g) * 2 - 1).to(dev)
+    p = random_fusion_params(d, dev, 11)
+    h = torch.empty((n, t, d), device=dev)
+    gates = torch.empty((n, t, 4 * d), device=dev)
+    cell = torch.empty((n, t, d), device=dev)
+    ops.check(lib.sagnn_lstm_fwd_train_f32(x.data_ptr(), t * d, d, n, t, d, p["lstm_W"].data_ptr(), p["lstm_b"].data_ptr(), 1.0, None,
+                                           h.data_ptr(), t * d, gates.data_ptr(), cell.data_ptr(), None))
+    scale = torch.from_numpy(_row_scales(n, rng, pattern).astype(np.float32)).to(dev)
+    dh = torch.randn((n, t, d), generator=g).to(dev) * scale[:, None, None]
+    outs = []
+    for use_ws in (False, True):
+        dx = torch.empty((n, t, d), device=dev)
+        dW = torch.zeros((2 * d, 4 * d), device=dev)
+        db = torch.zeros(4 * d, device=dev)
+        nbytes = int(lib.sagnn_lstm_bwd_workspace_bytes(n, t, d))
+        assert nbytes == n * t * 4 * d * 4
+        ws = torch.zeros(nbytes // 4, device=dev) if use_ws else None
+        ops.range_redo_count(reset=True)
+        ops.check(lib.sagnn_lstm_bwd_ws_f32(x.data_ptr(), t * d, d, h.data_ptr(), gates.data_ptr(), cell.data_ptr(), dh.data_ptr(), t * d,
+                                            None, p["lstm_W"].data_ptr(), dx.data_ptr(), dW.data_ptr(), db.data_ptr(), n, t, d,
+                                            ops._ptr(ws), nbytes if use_ws else 0, None))
+        outs.append((dx, dW, db, ws))
+    (dx0, dW0, db0, _), (dx1, dW1, db1, ws) = outs
+    assert torch.equal(dx0, dx1)
+    torch.testing.assert_close(db1, db0, rtol=1e-5, atol=1e-6 * float(db0.abs().max()))      # float atomics: order differs
+    dG = ws.view(t, n, 4 * d).double()                                                   # time-major
+    xh = torch.cat([x.permute(1, 0, 2), torch.cat([torch.zeros((1, n, d), device=dev), h.permute(1, 0, 2)[:-1]])], dim=2).double()
+    want = torch.einsum("tnk,tng->kg", xh, dG)
+    mag = torch.einsum("tnk,tng->kg", xh.abs(), dG.abs())
+    assert float(mag.max()) > 0
+    for name, got in (("second pass", dW1), ("one launch", dW0)):
+        err = (got.double() - want).abs()
+        assert bool((err <= 1e-6 * mag + 1e-30).all()), f"{name} [{pattern}]: worst {float((err / (mag + 1e-300)).max()):.3e} of sum |terms|"
+    # rows are met step by step (time-major): 'blocks' and 'rising' start every step 1e12 .. 1e50 above where the previous
+    # one ended, and the chunks at such a jump take the fp32 path by design (the scale follows by 2^16 per chunk)
+    if pattern in ("mixed", "tiny"):
+        assert ops.range_redo_count() <= max(2, n * t // 32 // 50), "ordinary gradient rows must stay on the matrix cores"
+
+
 @pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("d,t,n", [(64, 3, 2_000), (64, 16, 700), (32, 4, 1_500), (128, 3, 900), (64, 2, 40_003)])
 def test_lstm_small_inputs_keep_their_own_accuracy(dev, d, t, n, engine):

@@ -29,7 +29,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in sagnn.h but not exported by libsagnn.so"
     assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES table out of sync with sagnn.h"
-    assert lib.sagnn_version() == 10301
+    assert lib.sagnn_version() == 10302
 
 
 def test_csr_check_errors():
