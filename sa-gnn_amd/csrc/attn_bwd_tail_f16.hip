@@ -19,6 +19,13 @@
 // row factors. dQKV is a gradient of arbitrary scale: its rows enter the images at exact power-of-two scales (GRADIENT
 // RANGE below), so dy is accurate per row and dW / db relative to the sum of their terms' magnitudes at any scale.
 // A chunk the window cannot hold takes no part in the MFMAs: the block evaluates it with fp32 fmaf chains (a W out of range: every chunk).
+//
+// The same kernel in its LSTM form (NX = 2, NQ = 4, no dy; lstm_dw_f16 below) takes the weight gradient of the interval LSTM
+// (reference model.py:135-146 differentiated) from the gate gradients that the BPTT launch stored time-major:
+//   dW [2D, 4D] += sum over steps s and nodes of [x_s | h_{s-1}]^T dG_s
+// rows are (step, node) pairs, the left operand's two blocks come from x (its node / interval strides) and from h one
+// step back (zero at s = 0), and each of a wave's 16 dW tiles keeps ONE accumulator: the two cross products of a chunk go
+// through a transient tile that is folded in while the next tile's MFMAs run.
 #include "common.h"
 #include "f16_split.h"
 
