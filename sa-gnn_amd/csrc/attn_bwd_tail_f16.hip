@@ -230,6 +230,19 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
     for (int v = NX; v < NS; ++v) mx = max3abs(max3abs(mx, stage[v].x, stage[v].y), stage[v].z, stage[v].w);
     return group_max<LPRW>(__builtin_bit_cast(int, mx)) >> 23;
   };
+  // What the running scale E follows. The attention tail's left operand is a layer-normed row (O(1)): the gradient row's
+  // exponent alone. The LSTM's x | h rows have no such scale (hub rows of a propagated embedding reach 1e4): E follows the
+  // exponent of the PRODUCT of the two rows' maxima, so that the left row, scaled by 2^(k - E + kUp), stays below 2^(kUp + 1)
+  // whenever its row is no heavier than E — the factor every term carries, 2^(127 - E + kUp), does not depend on which
+  // exponent E follows.
+  auto row_weight = [&](int e) -> int {
+    if constexpr (DY) return e;
+    float mx = 0.f;
+#pragma unroll
+    for (int v = 0; v < NX; ++v) mx = max3abs(max3abs(mx, stage[v].x, stage[v].y), stage[v].z, stage[v].w);
+    const int kx = group_max<LPRW>(__builtin_bit_cast(int, mx)) >> 23;
+    return kx == 0 ? 0 : e + kx - 127;                  // an all-zero left row weighs nothing
+  };
   // split the staged row into buffer `b` at the scales described above; `id` = chunk number + 1 marks the buffer for the fp32 path
   auto commit = [&](int b, int id, int e, int E) {
     char* const buf = lds + b * BUF;
@@ -247,7 +260,10 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
       *reinterpret_cast<i32x2*>(dst + v * SUB + PIECE) = i32x2{tail2(p0, yv.x, yv.y, k4096), tail2(p1, yv.z, yv.w, k4096)};
       const float ys = maxabs_acc(maxabs3(yr.x, yr.y, yr.z), yr.w);       // the raw segment: small as a whole?
       const float yt = maxabs_acc(maxabs3(yv.x, yv.y, yv.z), yv.w);       // the scaled one: does it fit?
-      bad = bad || yt >= kF16Lim || (ys > 0.f && ys < 6.103515625e-05f);
+      // DY: y's scale is not part of what E follows, so a y segment that is small as a whole would lose its terms to the split's
+      // floor. LSTM form: E follows the weight of the PRODUCT, a small x | h segment (a saturated gate leaves h = 1e-14 next
+      // to 0.9) is small against the heaviest row's terms, which is all the floor is measured against.
+      bad = bad || yt >= kF16Lim || (DY && ys > 0.f && ys < 6.103515625e-05f);
     }
 #pragma unroll
     for (int v = NX; v < NS; ++v) {
@@ -274,7 +290,8 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
   if (ch < n_chunks) {
     fetch(ch);
     const int e = row_exponent();
-    if (sc == 0) ktab[sr] = e > 253 ? 253 : e < 1 ? 1 : e;
+    const int ew = row_weight(e);
+    if (sc == 0) ktab[sr] = ew > 253 ? 253 : ew < 1 ? 1 : ew;
     __syncthreads();
     // the first chunk is scaled against its own largest row, but no more than 2^kJump above its 4th largest
     int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
@@ -286,7 +303,8 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
       a = t2 > v ? t2 : v, v = t2 > v ? v : t2, t2 = a;
       t3 = t3 > v ? t3 : v;
     }
-    e_run = t0 < t3 + kJump ? t0 : t3 + kJump;
+    // (the LSTM form scales every chunk against a maximum that includes its OWN rows — see the loop — and needs no cap)
+    e_run = (!DY || t0 < t3 + kJump) ? t0 : t3 + kJump;
     commit(0, (int)(ch + 1), e, e_run);
   }
   __syncthreads();
@@ -419,9 +437,22 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
       const int ec = emax[slot];                        // chunk ch's own rows: complete since the barrier that closed its commit
       e_next = ec > e_run ? ec : e_run;
       const int e = row_exponent();
-      if (sc == 0) {                                    // what chunk nxt's rows ask of the chunk after it
-        const int k = e > 253 ? 253 : e < 1 ? 1 : e;
-        atomicMax(emax + nslot, k < e_next + kJump ? k : e_next + kJump);
+      const int ew = row_weight(e);
+      if constexpr (DY) {
+        if (sc == 0) {                                    // what chunk nxt's rows ask of the chunk after it
+          const int k = ew > 253 ? 253 : ew < 1 ? 1 : ew;
+          atomicMax(emax + nslot, k < e_next + kJump ? k : e_next + kJump);
+        }
+      } else {
+        // LSTM form: row weights are heavy-tailed (a hub node's row is 2^25 heavier than its neighbours'), and a chunk scaled
+        // against a maximum that lags by one chunk would overflow and take the fp32 path at every such row — once per block
+        // and launch at least. One more barrier per chunk and the chunk's own rows are in the maximum it is scaled against:
+        // nothing overflows, so nothing caps the step either (an absurd finite row makes the rows after it negligible in
+        // the sum it dominates, which is what they are).
+        if (sc == 0) atomicMax(emax + nslot, ew > 253 ? 253 : ew < 1 ? 1 : ew);
+        __syncthreads();
+        const int own = emax[nslot];
+        e_next = own > e_next ? own : e_next;
       }
       commit(cur ^ 1, (int)(nxt + 1), e, e_next);
     }

@@ -19,3 +19,10 @@ for d in prof_default prof_train prof_gowalla-shaped prof_amazon-shaped prof_mov
 rm -rf $O/pmc_sq $O/prof_*/
 st done
 cat $O/status.txt
+timeout -k 10 200 python3 bench.py --workload yelp-shaped --stages train --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_yelp-shaped_train.json 2> $O/train_yelp.err; st "train yelp rc $?"
+timeout -k 10 200 python3 bench.py --workload yelp-shaped --steps 20 --warmup 3 --graph --no-cpu-baseline > $O/bench_yelp-shaped_graph.json 2> $O/graph_yelp.err; st "graph yelp rc $?"
+for wl in gowalla-shaped amazon-shaped movielens-shaped; do
+  timeout -k 10 200 python3 bench.py --workload $wl --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_${wl}_eager.json 2> $O/eager_$wl.err; st "eager $wl rc $?"
+  timeout -k 10 200 python3 bench.py --workload $wl --steps 50 --warmup 5 --graph --no-cpu-baseline > $O/bench_${wl}_graph.json 2> $O/graph_$wl.err; st "graph $wl rc $?"
+done
+cat $O/status.txt
