@@ -196,6 +196,45 @@ def test_lstm_weight_gradient_pass_at_any_gradient_scale(dev, d, t, n, pattern):
         assert ops.range_redo_count() <= max(2, n * t // 32 // 50), "ordinary gradient rows must stay on the matrix cores"
 
 
+@pytest.mark.parametrize("d,t,n", [(64, 6, 9_001), (32, 4, 5_003), (64, 4, 19)])
+def test_lstm_weight_gradient_pass_with_an_output_dropout_mask(dev, d, t, n):
+    """The second-pass form under DropoutWrapper(output_keep_prob) (reference model.py:141-144): the mask scales the gradient
+    arriving at the emitted h inside the BPTT launch, the weight-gradient pass reads the UN-dropped h as the one-launch kernel
+    does. dx bit for bit, dW / db against the one-launch kernel."""
+    from sa_gnn_amd import _lib, ops
+    from sa_gnn_amd.model import random_fusion_params
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(d + t + n)
+    x = (torch.rand((n, t, d), generator=g) * 2 - 1).to(dev)
+    p = random_fusion_params(d, dev, 5)
+    drop = ((torch.rand((n, t, d), generator=g) < 0.5).float() * 2.0).to(dev)
+    h = torch.empty((n, t, d), device=dev)
+    gates = torch.empty((n, t, 4 * d), device=dev)
+    cell = torch.empty((n, t, d), device=dev)
+    ops.check(lib.sagnn_lstm_fwd_train_f32(x.data_ptr(), t * d, d, n, t, d, p["lstm_W"].data_ptr(), p["lstm_b"].data_ptr(), 1.0, None,
+                                           h.data_ptr(), t * d, gates.data_ptr(), cell.data_ptr(), None))
+    dh = torch.randn((n, t, d), generator=g).to(dev)
+    outs = []
+    for use_ws in (False, True):
+        dx, dW, db = torch.empty((n, t, d), device=dev), torch.zeros((2 * d, 4 * d), device=dev), torch.zeros(4 * d, device=dev)
+        nbytes = int(lib.sagnn_lstm_bwd_workspace_bytes(n, t, d))
+        ws = torch.empty(nbytes // 4, device=dev) if use_ws else None
+        ops.check(lib.sagnn_lstm_bwd_ws_f32(x.data_ptr(), t * d, d, h.data_ptr(), gates.data_ptr(), cell.data_ptr(), dh.data_ptr(), t * d,
+                                            drop.data_ptr(), p["lstm_W"].data_ptr(), dx.data_ptr(), dW.data_ptr(), db.data_ptr(), n, t, d,
+                                            ops._ptr(ws), nbytes if use_ws else 0, None))
+        outs.append((dx, dW, db))
+    assert torch.equal(outs[0][0], outs[1][0])
+    dG = ws.view(t, n, 4 * d).double().abs()                  # what the second pass read: the size of the sums' terms
+    xh = torch.cat([x.permute(1, 0, 2), torch.cat([torch.zeros((1, n, d), device=dev), h.permute(1, 0, 2)[:-1]])], dim=2).double().abs()
+    mag = torch.einsum("tnk,tng->kg", xh, dG)
+    assert bool(((outs[1][1] - outs[0][1]).abs().double() <= 2e-6 * mag + 1e-30).all())
+    assert bool(((outs[1][2] - outs[0][2]).abs().double() <= 2e-6 * dG.sum((0, 1)) + 1e-30).all())
+    with pytest.raises(_lib.SagnnError):                      # a scratch that is too small is an error, not a silent fallback
+        ops.check(lib.sagnn_lstm_bwd_ws_f32(x.data_ptr(), t * d, d, h.data_ptr(), gates.data_ptr(), cell.data_ptr(), dh.data_ptr(), t * d,
+                                            drop.data_ptr(), p["lstm_W"].data_ptr(), dx.data_ptr(), dW.data_ptr(), db.data_ptr(), n, t, d,
+                                            ws.data_ptr(), 16, None))
+
+
 @pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("d,t,n", [(64, 3, 2_000), (64, 16, 700), (32, 4, 1_500), (128, 3, 900), (64, 2, 40_003)])
 def test_lstm_small_inputs_keep_their_own_accuracy(dev, d, t, n, engine):
