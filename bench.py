@@ -137,6 +137,11 @@ def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(a.gpus, sys.argv[1:]))
+    # stdout carries ONE line, the result: whatever the libraries under this process print there (RCCL writes a five-line
+    # version banner to stdout when its communicator comes up) is sent to stderr, and the line goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -709,10 +714,12 @@ def main():
                                      "worst_over_tolerance": max(c["worst_over_tolerance"] for c in checks.values()),
                                      "what": "fused embeddings rows 0..S-1 of users and of items of the timed run (LSTM -> LN -> MHSA -> "
                                              "mean) vs oracle/selfgnn_oracle.py interval_fusion on the same propagated rows"}
-    if rank == 0:
-        print(json.dumps(result), flush=True)
     if multi:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    if rank == 0:
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
+    os.close(result_fd)
 
 
 if __name__ == "__main__":
