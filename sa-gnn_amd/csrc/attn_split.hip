@@ -9,7 +9,8 @@
 // attention phase (VALU + LDS latency) runs beside the other's products (matrix pipe).
 //   fill + layer norm: 16 threads per row (float4 each). Moments per row around the row's own mean
 //     (two passes in registers), combined over the T rows of a node with the exact pairwise
-//     formula (M2 = sum M2_r + d sum (mean_r - mean)^2): two workgroup barriers, no cancellation.
+//     formula (M2 = sum M2_r + d sum (mean_r - mean)^2): two workgroup barriers, no cancellation — or, at d = 64 with T a
+//     power of two, inside one wave through lane shuffles (WL below).
 //     The normalised rows go to LDS as two f16 images [64][d] (B fragments).
 //   Q|K|V: transposed product (W^T y^T). Wave w owns output columns 16w..16w+15 of EACH of Q, K, V
 //     — with 16 heads these are whole heads — and keeps that slice of Wq/Wk/Wv in registers as A
