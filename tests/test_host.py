@@ -124,6 +124,29 @@ def test_fusion_argument_errors_without_gpu():
                                       None, 64, None, 0, None) == -1
 
 
+def test_round3_entries_reject_bad_arguments_without_gpu():
+    """The entries added in round 3 validate before they touch a device: segmented weight gradient, BPTT with scratch."""
+    lib = _lib.load()
+    buf = (ctypes.c_float * 4096)()
+    p = ctypes.addressof(buf)
+    # dense_tn_seg: din / dout multiples of 32, 16-byte rows, segment strides multiples of 4 floats, dW given
+    assert lib.sagnn_dense_tn_seg_f32(p, 64, 4096, p, 128, 4096, 10, 3, 48, 128, p, None, None) == -2
+    assert lib.sagnn_dense_tn_seg_f32(p, 64, 4098, p, 128, 4096, 10, 3, 64, 128, p, None, None) == -3
+    assert lib.sagnn_dense_tn_seg_f32(p, 62, 4096, p, 128, 4096, 10, 3, 64, 128, p, None, None) == -3
+    assert lib.sagnn_dense_tn_seg_f32(p, 64, 4096, p, 128, 4096, 10, 3, 64, 128, None, None, None) == -1
+    assert lib.sagnn_dense_tn_seg_f32(p, 64, 4096, p, 128, 4096, 0, 3, 64, 128, p, None, None) == 0      # nothing to add
+    # lstm_bwd_ws: the scratch size is the gate gradients', a short one is an error (not a silent one-launch fallback)
+    assert lib.sagnn_lstm_bwd_workspace_bytes(1000, 5, 64) == 1000 * 5 * 256 * 4
+    assert lib.sagnn_lstm_bwd_workspace_bytes(0, 5, 64) == 0
+    args = (p, 320, 64, p, p, p, p, 320, None, p, p, p, p, 10, 5)
+    assert lib.sagnn_lstm_bwd_ws_f32(*args, 64, p, 16, None) == -6
+    assert lib.sagnn_lstm_bwd_ws_f32(*args, 48, p, 1 << 20, None) == -2
+    assert lib.sagnn_lstm_bwd_ws_f32(p, 320, 64, None, p, p, p, 320, None, p, p, p, p, 10, 5, 64, p, 1 << 20, None) == -1
+    msg = ctypes.create_string_buffer(256)
+    lib.sagnn_last_error(msg, 256)
+    assert b"null" in msg.value.lower()
+
+
 def test_params_match_reference_flags():
     from sa_gnn_amd import Params
     a = Params.parse_args([])
