@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Randomised sweep of the GPU parity tests: calls the test functions of tests/test_gpu_*.py with parameters drawn at random
+(shapes the parametrised lists do not contain) for a fixed time budget, prints every failure with its parameters.
+
+    python tools/fuzz_gpu.py --seconds 300 --seed 1
+"""
+import argparse
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args()
+    import torch
+    import test_gpu_backward as tb
+    import test_gpu_dense as td
+    import test_gpu_f16_range as tr
+    import test_gpu_fusion as tf
+    import test_gpu_fusion_multitile as tm
+    dev = torch.device("cuda:0")
+    rnd = random.Random(a.seed)
+    T_FAST = [1, 2, 3, 4, 5, 6, 8, 12, 16]
+
+    def n_(lo=1, hi=5000):
+        return rnd.choice([rnd.randint(lo, 40), rnd.randint(lo, hi), rnd.choice([31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 191, 193])])
+
+    cases = [
+        ("lstm_vs_oracle", lambda: tf.test_lstm_vs_oracle(dev, rnd.choice([32, 64, 128]), rnd.choice(T_FAST + [7, 9]), n_())),
+        ("mhsa_mean_vs_oracle", lambda: tf.test_mhsa_mean_vs_oracle(dev, rnd.choice([32, 64, 128]), 16, rnd.choice(T_FAST + [7, 10]), n_(1, 2000))),
+        ("interval_fusion_vs_oracle", lambda: tf.test_interval_fusion_vs_oracle(dev, rnd.choice([32, 64, 128]), rnd.choice(T_FAST), n_(1, 3000))),
+        ("position_independence", lambda: tf.test_a_rows_result_does_not_depend_on_its_position_in_a_tile(dev, rnd.choice([32, 64]), rnd.choice(T_FAST))),
+        ("fusion_backward", lambda: tb.test_interval_fusion_backward_vs_autograd(dev, rnd.choice([32, 64, 128]), rnd.choice([1, 2, 3, 4, 5, 6]), n_(1, 400), 16)),
+        ("fusion_backward_longT", lambda: tb.test_interval_fusion_backward_vs_autograd(dev, rnd.choice([32, 64]), rnd.choice([8, 12, 16]), n_(1, 200), 16)),
+        ("dense_nn", lambda: td.test_dense_nn(dev, n_(1, 6000), 32 * rnd.randint(1, 16), 32 * rnd.randint(1, 16))),
+        ("dense_tn", lambda: td.test_dense_tn(dev, n_(1, 20000), 32 * rnd.randint(1, 12), 32 * rnd.randint(1, 16))),
+        ("dense_tn_seg", lambda: td.test_dense_tn_seg(dev, n_(1, 3000), rnd.randint(1, 12), 32 * rnd.randint(1, 6), 32 * rnd.randint(1, 16),
+                                                     rnd.choice(["node", "time"]))),
+        ("attn_bwd_tail", lambda: td.test_attn_bwd_tail(dev, n_(1, 50000), rnd.choice([32, 64]), rnd.choice(["f16x2", "f32"]))),
+        ("tail_any_scale", lambda: tr.test_attn_bwd_tail_rows_of_any_scale(dev, n_(33, 30000), rnd.choice([32, 64]),
+                                                                           rnd.choice(["blocks", "mixed", "rising", "falling", "tiny", "needle"]), "f16x2")),
+        ("lstm_dw_any_scale", lambda: tr.test_lstm_weight_gradient_pass_at_any_gradient_scale(dev, rnd.choice([32, 64]), rnd.randint(1, 9), n_(1, 9000),
+                                                                                              rnd.choice(["blocks", "mixed", "tiny"]))),
+        ("lstm_dw_dropout", lambda: tr.test_lstm_weight_gradient_pass_with_an_output_dropout_mask(dev, rnd.choice([32, 64]), rnd.randint(1, 8), n_(1, 5000))),
+        ("attn_bwd_front", lambda: tm.test_attn_bwd_front_many_tiles_per_block(dev, *rnd.choice([(64, rnd.choice(T_FAST)), (32, rnd.choice(T_FAST)),
+                                                                                 (128, rnd.choice([1, 2, 3, 4, 5, 6]))]), n_(1, 6000))),
+    ]
+    import functools
+
+    def traced(mod):
+        """Wrap every test function of a module so that a failure can name the arguments it was called with."""
+        for nm in dir(mod):
+            f = getattr(mod, nm)
+            if nm.startswith("test_") and callable(f):
+                def w(*args, _f=f, _nm=nm, **kw):
+                    last["call"] = f"{_nm}{args[1:]}"
+                    return _f(*args, **kw)
+                setattr(mod, nm, functools.wraps(f)(w))
+
+    last = {"call": ""}
+    for m in (tb, td, tr, tf, tm):
+        traced(m)
+    t_end = time.time() + a.seconds
+    runs = fails = 0
+    state = None
+    while time.time() < t_end:
+        name, fn = rnd.choice(cases)
+        state = rnd.getstate()
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            fails += 1
+            print(f"FAIL {last['call']}: {type(e).__name__}: {str(e)[:300]}", flush=True)
+        runs += 1
+        if runs % 25 == 0:
+            print(f"[fuzz] {runs} runs, {fails} failures", flush=True)
+    print(f"[fuzz] done: {runs} runs, {fails} failures (seed {a.seed})", flush=True)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
