@@ -68,12 +68,55 @@ def main():
     last = {"call": ""}
     for m in (tb, td, tr, tf, tm):
         traced(m)
+    def spmm_case():
+        """Random interval graphs (hub rows / columns, empty rows, an empty interval now and then), random plan thresholds, any
+        d the SpMM takes; the per-interval entry and the batched entry against the oracle and against each other."""
+        import numpy as np
+        import scipy.sparse as sp
+        import test_gpu_spmm as ts
+        from oracle import selfgnn_oracle as O
+        from sa_gnn_amd import graph, ops
+        rng = np.random.default_rng(rnd.randrange(1 << 30))
+        U, I, T, L = rnd.randint(1, 400), rnd.randint(1, 300), rnd.randint(1, 5), rnd.randint(1, 3)
+        d = rnd.choice([4, 8, 16, 32, 48, 64, 96, 128, 256])
+        short, long_, chunk = rnd.choice([(2, 4, 32), (4, 8, 64), (8, 24, 64), (16, 256, 256), (8, 16, 32)])
+        last["call"] = f"spmm_case(U={U}, I={I}, T={T}, L={L}, d={d}, tuning={(short, long_, chunk)})"
+        mats = []
+        for k in range(T):
+            m = (rng.random((U, I)) < rnd.choice([0.0, 0.01, 0.05, 0.2])).astype(np.intc)
+            if rnd.random() < 0.5:
+                m[rnd.randrange(U), :] = 1
+            if rnd.random() < 0.5:
+                m[:, rnd.randrange(I)] = 1
+            if rnd.random() < 0.3 and U > 3:
+                m[U // 2:, :] = 0
+            mats.append(sp.csr_matrix(m))
+        pairs = [graph.interval_pair(m, dev, tuning=(short, long_, chunk)) for m in mats]
+        ue = rng.standard_normal((T, U, d)).astype(np.float32)
+        ie = rng.standard_normal((T, I, d)).astype(np.float32)
+        ued, ied = torch.from_numpy(ue).to(dev), torch.from_numpy(ie).to(dev)
+        adjs = [O.trans_to_lsts(m)[0] for m in mats]
+        tps = [O.trans_to_lsts(O.transpose(m))[0] for m in mats]
+        want_u, want_i = O.gnn_stack(ue, ie, adjs, tps, L, 0.5)
+        terms_u, terms_i = O.gnn_stack(np.abs(ue), np.abs(ie), adjs, tps, L, 1.0)
+        us, its = torch.empty((U, T, d), device=dev), torch.empty((I, T, d), device=dev)
+        for k in range(T):
+            ops.gnn_interval(pairs[k][0].plan, pairs[k][1].plan, ued[k], ied[k], L, 0.5, us[:, k, :], its[:, k, :])
+        ts.assert_sum_close(us.cpu().numpy(), want_u, terms_u)
+        ts.assert_sum_close(its.cpu().numpy(), want_i, terms_i)
+        batch = ops.SpmmBatch([p_[0].plan for p_ in pairs], [p_[1].plan for p_ in pairs])
+        us2, its2 = torch.empty((U, T, d), device=dev), torch.empty((I, T, d), device=dev)
+        ops.gnn_stack(batch, ued, ied, L, 0.5, us2.permute(1, 0, 2), its2.permute(1, 0, 2))
+        assert torch.equal(us, us2) and torch.equal(its, its2), "batched entry differs from the per-interval entry"
+
+    cases.append(("spmm", spmm_case))
+    cases.append(("spmm", spmm_case))            # the path's own kernel: drawn twice as often
     t_end = time.time() + a.seconds
     runs = fails = 0
-    state = None
+    counts = {}
     while time.time() < t_end:
         name, fn = rnd.choice(cases)
-        state = rnd.getstate()
+        counts[name] = counts.get(name, 0) + 1
         try:
             fn()
         except Exception as e:  # noqa: BLE001
@@ -82,7 +125,7 @@ def main():
         runs += 1
         if runs % 25 == 0:
             print(f"[fuzz] {runs} runs, {fails} failures", flush=True)
-    print(f"[fuzz] done: {runs} runs, {fails} failures (seed {a.seed})", flush=True)
+    print(f"[fuzz] done: {runs} runs, {fails} failures (seed {a.seed}); per case: {dict(sorted(counts.items()))}", flush=True)
     sys.exit(1 if fails else 0)
 
 
