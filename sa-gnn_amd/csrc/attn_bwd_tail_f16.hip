@@ -92,8 +92,9 @@ __device__ __forceinline__ float pow2_field(int field) {   // 2^(field - 127), 0
 // every row matters on its own, because dy feeds per-row chains (layer-norm backward, BPTT, embedding rows) and
 // Adam is scale-free per element. The two-piece f16 split has an absolute floor of 2^-37 (f16_split.h), so the rows
 // are brought into its window by EXACT powers of two:
-//   * row r of the dQKV images holds dQKV[r] 2^(127 - k_r), k_r = the biased fp32 exponent of the row's max |.|
-//     (clamped to 1 .. 253): the row's max is in [1, 2) (below 4 at the clamp). dy[r] is descaled by 2^(k_r - 127)
+//   * row r of the dQKV images holds dQKV[r] 2^(127 - k_r + kGUp), k_r = the biased fp32 exponent of the row's max |.|
+//     (clamped to kGUp + 1 .. 253): the row's max is in [2^kGUp, 2^(kGUp + 1)) (below 2^(kGUp + 2) at the clamp), the top
+//     of the window, so that the split's floor lies 2^-49 below it. dy[r] is descaled by 2^(k_r - 127 - kGUp)
 //     at its store — per-row accuracy is that of rows of magnitude one, at any scale.
 //   * dW = sum_r y[r]^T dQKV[r] needs one scale for all rows, so row r of the y image holds y[r] 2^(k_r - E + kUp):
 //     every term arrives as y dQKV 2^(127 - E + kUp); E follows the largest k the block has met (its accumulators
@@ -109,6 +110,12 @@ __device__ __forceinline__ float pow2_field(int field) {   // 2^(field - 127), 0
 //     (2e30 in a field of ones) goes through the fp32 path without wiping out the rows after it.
 constexpr int kUp = 6, kJump = 16;
 constexpr float kUpInv = 1.f / 64.f;   // 2^-kUp
+// A gradient row enters the images with its maximum in [2^kGUp, 2^(kGUp + 1)), not in [1, 2): the split's absolute floor
+// (2^-37) then sits 2^-(37 + kGUp) below the row's maximum, so a COLUMN that is small in every row (a saturated gate's
+// gradient: 2^-18 of its row's maximum and less) keeps its own relative accuracy in dW — found by tools/fuzz_gpu.py as
+// 1.3e-6 of such an element's terms with the rows at [1, 2). 2^13 stays two binades under the window's top (32768).
+constexpr int kGUp = 12;
+constexpr float kGUpInv = 1.f / 4096.f;   // 2^-kGUp
 
 // Where the rows come from. The attention tail (DY): one segment, x0 = y [rows, D] (overwritten with dy), g = dQKV [rows, 3 D].
 // The LSTM weight gradient (NX = 2, NQ = 4, no dy): row r = (s, i) = (step, node), s = r / seg_rows; block 0 of the left
@@ -246,8 +253,8 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
   // split the staged row into buffer `b` at the scales described above; `id` = chunk number + 1 marks the buffer for the fp32 path
   auto commit = [&](int b, int id, int e, int E) {
     char* const buf = lds + b * BUF;
-    const int k = e > 253 ? 253 : e < 1 ? 1 : e;
-    const float s = pow2_field(254 - k);               // dQKV row scale
+    const int k = e > 253 ? 253 : e < kGUp + 1 ? kGUp + 1 : e;
+    const float s = pow2_field(254 - k + kGUp);        // dQKV row scale: 2^(127 - k + kGUp)
     const float f = pow2_field(127 + k - E + kUp);     // y row scale
     char* const dst = buf + img_off<D>(sr, sc >> 1) + (sc & 1) * 8;
     bool bad = e == 255;
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
       *reinterpret_cast<i32x2*>(dst + v * SUB + PIECE) = i32x2{t0, t1};
     }
     if (sc == 0) {
-      inv[b * kRows + sr] = pow2_field(k);
+      inv[b * kRows + sr] = pow2_field(k - kGUp);      // 2^(k - 127 - kGUp): dy's descale
       const int oh = head2(f, 0.f);
       const int ot = tail2(oh, f, 0.f, k4096);
       *reinterpret_cast<short*>(ones + (b * 2 + 0) * (kRows * 2) + sr * 2) = (short)oh;
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
 
   // ---- flush: the accumulators hold the sums times 2^(127 - e_acc + kUp) --------------------------------------
   if (e_acc == 0) return;   // nothing went through the matrix cores
-  const float u1 = pow2_field(e_acc), u2 = kUpInv;
+  const float u1 = pow2_field(e_acc), u2 = kUpInv * kGUpInv;
 #pragma unroll
   for (int a = 0; a < MB; ++a)
 #pragma unroll
