@@ -311,6 +311,8 @@ __global__ __launch_bounds__(D == 64 ? 512 : 256, D == 64 ? 1 : 2) void attn_bwd
       t3 = t3 > v ? t3 : v;
     }
     // (the LSTM form scales every chunk against a maximum that includes its OWN rows — see the loop — and needs no cap)
+    // (a ragged last chunk of fewer than four rows that is a block's FIRST chunk has padding rows standing in for its 4th
+    // largest: its rows then take the fp32 path — exact, and the only safe choice with nothing to measure an absurd row against)
     e_run = (!DY || t0 < t3 + kJump) ? t0 : t3 + kJump;
     commit(0, (int)(ch + 1), e, e_run);
   }

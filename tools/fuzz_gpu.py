@@ -31,7 +31,7 @@ def main():
     T_FAST = [1, 2, 3, 4, 5, 6, 8, 12, 16]
 
     def n_(lo=1, hi=5000):
-        return rnd.choice([rnd.randint(lo, 40), rnd.randint(lo, hi), rnd.choice([31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 191, 193])])
+        return rnd.choice([rnd.randint(lo, max(lo, 40)), rnd.randint(lo, hi), max(lo, rnd.choice([31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 191, 193]))])
 
     cases = [
         ("lstm_vs_oracle", lambda: tf.test_lstm_vs_oracle(dev, rnd.choice([32, 64, 128]), rnd.choice(T_FAST + [7, 9]), n_())),
@@ -111,15 +111,33 @@ def main():
 
     cases.append(("spmm", spmm_case))
     cases.append(("spmm", spmm_case))            # the path's own kernel: drawn twice as often
+    eng = lambda: rnd.choice(["f16x2", "f16x2", "f32"])   # noqa: E731
+    cases += [
+        ("dx_any_scale", lambda: tr.test_fusion_backward_dx_per_node_at_any_gradient_scale(dev, rnd.choice([32, 64]), rnd.choice([1, 2, 3, 4, 5, 6]), n_(40, 4000), eng())),
+        ("lstm_small_inputs", lambda: tr.test_lstm_small_inputs_keep_their_own_accuracy(dev, rnd.choice([32, 64, 128]), rnd.choice(T_FAST[2:]), n_(300, 3000), eng())),
+        ("attention_small_inputs", lambda: tr.test_attention_small_inputs_keep_their_own_accuracy(dev, rnd.choice([32, 64, 128]), rnd.choice(T_FAST), n_(300, 3000), eng())),
+        ("tail_beyond_range", lambda: td.test_attn_bwd_tail_beyond_the_f16_range(dev, n_(40, 30000), rnd.choice([32, 64]))),
+        ("lstm_beyond_range", lambda: tm.test_lstm_inputs_beyond_the_f16_range(dev, rnd.choice([32, 64, 128]), rnd.choice(T_FAST[1:]), n_(700, 5000))),
+        ("attention_beyond_range", lambda: tm.test_attention_operands_beyond_the_f16_range(dev, rnd.choice([32, 64, 128]), rnd.choice(T_FAST[1:]), n_(300, 5000))),
+        ("lstm_continuation", lambda: tf.test_lstm_continuation_is_bit_identical(dev, rnd.choice([32, 64, 128]), n_(1, 3000))),
+        ("engines_agree", lambda: tm.test_split_engine_matches_f32_mfma_engine(dev, *rnd.choice([(64, rnd.choice(T_FAST)), (32, rnd.choice(T_FAST)),
+                                                                                  (128, rnd.choice([1, 2, 3, 4, 5, 6]))]), n_(1, 6000))),
+        ("training_fwd_bwd", lambda: tm.test_training_forward_and_backward_many_tiles_per_block(dev, rnd.choice([32, 64]), rnd.choice(T_FAST), n_(1, 3000))),
+    ]
     t_end = time.time() + a.seconds
     runs = fails = 0
     counts = {}
     while time.time() < t_end:
         name, fn = rnd.choice(cases)
         counts[name] = counts.get(name, 0) + 1
+        last["call"] = name
         try:
             fn()
-        except Exception as e:  # noqa: BLE001
+        except KeyboardInterrupt:
+            raise
+        except BaseException as e:  # noqa: BLE001  (pytest.skip raises outside Exception)
+            if type(e).__name__ == "Skipped":
+                continue
             fails += 1
             print(f"FAIL {last['call']}: {type(e).__name__}: {str(e)[:300]}", flush=True)
         runs += 1
