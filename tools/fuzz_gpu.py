@@ -122,7 +122,8 @@ def main():
         ("lstm_continuation", lambda: tf.test_lstm_continuation_is_bit_identical(dev, rnd.choice([32, 64, 128]), n_(1, 3000))),
         ("engines_agree", lambda: tm.test_split_engine_matches_f32_mfma_engine(dev, *rnd.choice([(64, rnd.choice(T_FAST)), (32, rnd.choice(T_FAST)),
                                                                                   (128, rnd.choice([1, 2, 3, 4, 5, 6]))]), n_(1, 6000))),
-        ("training_fwd_bwd", lambda: tm.test_training_forward_and_backward_many_tiles_per_block(dev, rnd.choice([32, 64]), rnd.choice(T_FAST), n_(1, 3000))),
+        # (T >= 2: with one key the attention weights are 1 whatever q and k are — dWq / dWk are fp32 noise around ~0 and the test's noise floor is a rule of thumb)
+        ("training_fwd_bwd", lambda: tm.test_training_forward_and_backward_many_tiles_per_block(dev, rnd.choice([32, 64]), rnd.choice(T_FAST[1:]), n_(1, 3000))),
     ]
     t_end = time.time() + a.seconds
     runs = fails = 0
