@@ -286,6 +286,14 @@ def main():
             if post:
                 ex_u.post(out_u[j].to(comm_dev))
                 ex_i.post(out_i[j].to(comm_dev))
+        if post:
+            # T not a multiple of world: a rank with one interval fewer takes part in the last round with empty sends — HERE, in
+            # the order every other rank posts it (users' round, items' round), not lazily when the fusion first waits for the
+            # round: by then the other ranks have issued the users' all-gather in between, and collectives issued in different
+            # orders on different ranks deadlock (found by tools/fuzz_ranks.py: world 3, T 8)
+            for _ in range(t_loc, sh.rounds):
+                ex_u.post(None)
+                ex_i.post(None)
 
     def fuse_pipelined():
         # Fusion pipelined with the exchange: the LSTM steps of a round run as soon as that round
