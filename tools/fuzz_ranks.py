@@ -36,12 +36,22 @@ def main():
         scale = rnd.choice([0.001, 0.002, 0.003])
         common = ["--scale", str(scale), "--no-cpu-baseline", "--intervals", str(T), "--stages", stages,
                   "--steps", "2" if stages == "train" else "1", "--warmup", "0" if stages == "train" else "1"]
-        tag = f"world {world}, T {T}, {stages}, split {split}, scale {scale}"
+        extra = []
+        wl = rnd.choice(["synthetic", "synthetic", "gowalla-shaped", "amazon-shaped", "yelp-shaped", "movielens-shaped"])
+        if wl != "synthetic":                       # the dataset shapes bring their own T (3 / 5 / 12 / 6) and L; full size is small
+            common = ["--workload", wl, "--no-cpu-baseline", "--stages", stages, "--steps", "2" if stages == "train" else "1",
+                      "--warmup", "0" if stages == "train" else "1"]
+            T = {"gowalla-shaped": 3, "amazon-shaped": 5, "yelp-shaped": 12, "movielens-shaped": 6}[wl]
+            split = rnd.choice(["fractional", "groups"]) if (T < world and stages != "train") else "fractional"
+        elif T >= world and stages == "full" and rnd.random() < 0.3:
+            extra = ["--exchange", "allgather"]
+        tag = f"{wl}: world {world}, T {T}, {stages}, split {split}, scale {scale}{' allgather' if extra else ''}"
         print(f"...  {tag}", flush=True)
         try:
             one = run(common)
-            many = run(["--gpus", str(world), "--dist-backend", "gloo", "--split", split] + common)
-            tol = 2e-5 if stages == "train" else (1e-6 if T < world else 0.0)
+            many = run(["--gpus", str(world), "--dist-backend", "gloo", "--split", split] + extra + common)
+            # dataset shapes run the batched stack at N = 1 and per-interval launches at N > 1: same sums, other association
+            tol = 2e-5 if stages == "train" else (1e-6 if (T < world or wl != "synthetic") else 0.0)
             worst = max(abs(x - y) / abs(x) for x, y in zip(one["final_abs_mean"] + one["final_position_checksum"],
                                                             many["final_abs_mean"] + many["final_position_checksum"]))
             ok = worst <= tol
