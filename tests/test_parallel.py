@@ -95,6 +95,61 @@ def test_interval_sharded_pipeline_matches_single_process(world, T, mode):
         np.testing.assert_allclose(results[r], want, rtol=1e-6, atol=1e-6)
 
 
+def _two_exchange_worker(rank, world, port, T, q):
+    """bench.py's N > 1 forward schedule on CPU tensors: both node types' exchange rounds posted interval by interval, the
+    users' all-gather issued while the items' last round is still in flight."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        U, I, d = 24, 18, 8
+        rng = np.random.default_rng(11)
+        ue = rng.standard_normal((T, U, d)).astype(np.float32)
+        ie = rng.standard_normal((T, I, d)).astype(np.float32)
+        sh = IntervalSharding(T, world, rank)
+        cpu = torch.device("cpu")
+        ex_u, ex_i = RowShardExchange(sh, U, d, cpu), RowShardExchange(sh, I, d, cpu)
+        for k in sh.local_intervals:
+            ex_u.post(torch.from_numpy(ue[k]))
+            ex_i.post(torch.from_numpy(ie[k]))
+        # a rank with one interval fewer joins the short last round HERE, in the order the others post it. Left to the
+        # first wait_round() of each exchange it would come after this rank's users' all-gather, which the other ranks issue
+        # AFTER their items' last round: the collectives then meet in different orders and the run hangs.
+        for _ in range(len(sh.local_intervals), sh.rounds):
+            ex_u.post(None)
+            ex_i.post(None)
+        fu = torch.cat([ex_u.wait_round(j) for j in range(sh.rounds)], 0).mean(0)      # a stand-in for the fusion of this rank's rows
+        full_u, fin_u = gather_fused(fu, sh, U, async_op=True)
+        fi = torch.cat([ex_i.wait_round(j) for j in range(sh.rounds)], 0).mean(0)
+        full_i = gather_fused(fi, sh, I)
+        full_u = fin_u()
+        ex_u.finish(), ex_i.finish()
+        q.put((rank, full_u.numpy(), full_i.numpy(), ue.mean(0), ie.mean(0)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T", [(3, 8), (2, 3), (3, 4)])
+@pytest.mark.timeout(120)
+def test_short_last_round_joins_in_collective_order(world, T):
+    """T not a multiple of the rank count with TWO exchanges and a gather in between (the schedule of bench.py): every
+    rank issues the same sequence of collectives. The GPU rehearsal of (3 ranks, T = 8) hung before the empty rounds were
+    posted eagerly (tools/fuzz_ranks.py)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_two_exchange_worker, args=(r, world, port, T, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    res = [q.get(timeout=100) for _ in range(world)]
+    for p_ in procs:
+        p_.join(timeout=30)
+        assert p_.exitcode == 0
+    for _, fu, fi, want_u, want_i in res:
+        np.testing.assert_allclose(fu, want_u, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(fi, want_i, rtol=1e-6, atol=1e-6)
+
+
 def test_sharding_maps():
     sh = IntervalSharding(16, 8, 3)
     assert sh.local_intervals == [3, 11] and sh.rounds == 2 and sh.owner(11) == 3
